@@ -1,0 +1,561 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite
+never import the reference -- they read the .npz files this script wrote.  The reference
+has no test-suite of its own, so these vectors are the parity pins.
+
+What it does
+  * installs `sys.modules` stand-ins for the reference's absent third-party deps
+    (monai, SimpleITK, nibabel, hydra, skimage) -- none of them is on the hot path's
+    arithmetic -- and replaces `torch.utils.cpp_extension.load` with a dummy BEFORE any
+    reference import, so the reference's CUDA extension is never hipified/JIT-built;
+  * `sys.dont_write_bytecode = True` so importing does not write into /root/reference;
+  * records an RNG tape (numpy global + torch global draws, in order);
+  * calls the reference functions on seeded inputs and stores inputs + outputs.
+
+Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import struct
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+
+
+# --------------------------------------------------------------------------------------
+# stand-ins for absent third-party modules
+# --------------------------------------------------------------------------------------
+def install_stubs():
+    import torch.utils.cpp_extension as cpp_ext
+
+    cpp_ext.load = lambda *a, **k: types.SimpleNamespace()  # never JIT the CUDA extension
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Transform:  # nominal base class only
+        pass
+
+    class _Identity:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x, *a, **k):
+            return x
+
+    class ScaleIntensity:
+        def __init__(self, minv=0.0, maxv=1.0):
+            self.minv, self.maxv = minv, maxv
+
+        def __call__(self, x):
+            mn, mx = x.min(), x.max()
+            if mn == mx:
+                return x * self.minv
+            return (x - mn) / (mx - mn) * (self.maxv - self.minv) + self.minv
+
+    class MetaTensor:  # must be a class (used in a `Tensor | MetaTensor` annotation)
+        pass
+
+    tr = mod(
+        "monai.transforms",
+        Transform=Transform,
+        Spacing=_Identity,
+        Orientation=_Identity,
+        ScaleIntensity=ScaleIntensity,
+        Compose=_Identity,
+    )
+    da = mod("monai.data", MetaTensor=MetaTensor)
+    mod("monai", transforms=tr, data=da)
+    mod("SimpleITK", ReadImage=None, GetArrayFromImage=None)
+    mod("nibabel")
+    hu = mod("hydra.utils", instantiate=None)
+    mod("hydra", utils=hu)
+    sm = mod("skimage.morphology", ball=None)
+    mod("skimage", morphology=sm)
+
+
+# --------------------------------------------------------------------------------------
+# RNG tape
+# --------------------------------------------------------------------------------------
+class Tape:
+    """Records every numpy-global / torch-global draw in call order."""
+
+    BIG = 4096
+
+    def __init__(self):
+        self.entries = []
+        self._orig = {}
+
+    def _rec(self, name, args, value):
+        v = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+        self.entries.append((name, args, v))
+
+    def __enter__(self):
+        tape = self
+
+        def wrap(owner, attr, name):
+            orig = getattr(owner, attr)
+            self._orig[(owner, attr)] = orig
+
+            def f(*a, **k):
+                out = orig(*a, **k)
+                tape._rec(name, repr((a, {kk: str(vv) for kk, vv in k.items()})), out)
+                return out
+
+            setattr(owner, attr, f)
+
+        for a in ("rand", "randn", "randint", "uniform"):
+            wrap(np.random, a, "np." + a)
+        for a in ("rand", "randn"):
+            wrap(torch, a, "torch." + a)
+        return self
+
+    def __exit__(self, *exc):
+        for (owner, attr), orig in self._orig.items():
+            setattr(owner, attr, orig)
+
+    def pack(self, prefix="tape"):
+        """dict of arrays: small draws stored whole, big ones as (shape, head, sum)."""
+        out = {f"{prefix}_n": np.int64(len(self.entries))}
+        names = []
+        for i, (name, _args, v) in enumerate(self.entries):
+            names.append(name)
+            v = np.asarray(v)
+            if v.size <= self.BIG:
+                out[f"{prefix}_{i}"] = v
+            else:
+                out[f"{prefix}_{i}_shape"] = np.asarray(v.shape, dtype=np.int64)
+                out[f"{prefix}_{i}_head"] = v.reshape(-1)[:16].copy()
+                out[f"{prefix}_{i}_sum"] = np.float64(v.astype(np.float64).sum())
+        out[f"{prefix}_names"] = np.asarray(names)
+        return out
+
+
+def read_nifti(path):
+    """Minimal NIfTI-1 (.nii.gz) reader: returns array in (x,y,z) order + pixdim."""
+    raw = gzip.open(path, "rb").read()
+    dim = struct.unpack("<8h", raw[40:56])
+    datatype = struct.unpack("<h", raw[70:72])[0]
+    pixdim = struct.unpack("<8f", raw[76:108])
+    vox_offset = int(struct.unpack("<f", raw[108:112])[0])
+    dt = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16}[datatype]
+    n = dim[1] * dim[2] * dim[3]
+    arr = np.frombuffer(raw, dtype=dt, count=n, offset=vox_offset).reshape(dim[3], dim[2], dim[1])
+    return np.ascontiguousarray(arr.transpose(2, 1, 0)), pixdim[1:4]
+
+
+def save(name, **arrays):
+    path = HERE / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path.name}: {path.stat().st_size/1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# --------------------------------------------------------------------------------------
+# individual golden sets
+# --------------------------------------------------------------------------------------
+def g_affine(R):
+    rng = np.random.default_rng(11)
+    rots = np.concatenate([np.zeros((1, 3)), rng.uniform(-0.35, 0.35, (4, 3))])
+    shs = np.concatenate([np.zeros((1, 3)), rng.uniform(-0.02, 0.02, (4, 3))])
+    scs = np.concatenate([np.ones((1, 3)), rng.uniform(0.9, 1.1, (4, 3))])
+    A = np.stack([R.gen.make_affine_matrix(r, s, c) for r, s, c in zip(rots, shs, scs)])
+    save("affine", rot=rots, shear=shs, scale=scs, A=A)
+
+
+def g_gauss(R):
+    sig = np.array([0.3, 0.44, 0.87, 1.0, 1.77, 5.0])
+    out = {"sigma": sig}
+    for i, s in enumerate(sig):
+        out[f"taps_{i}"] = R.gen.make_gaussian_kernel(float(s), "cpu").numpy()
+    save("gauss_taps", **out)
+
+
+def g_blur(R):
+    rng = np.random.default_rng(21)
+    out = {}
+    stds = np.array([[1.2, 0.0, 0.7], [1.77, 1.77, 1.77], [0.3, 0.3, 0.3], [5.0, 5.0, 5.0], [0.0, 0.9, 0.0]])
+    out["stds"] = stds
+    for si, shape in enumerate([(24, 20, 16), (48, 48, 48), (7, 33, 10)]):
+        x = (rng.random(shape, dtype=np.float32) * 255).astype(np.float32)
+        out[f"x_{si}"] = x
+        for ti, st in enumerate(stds):
+            y = R.gen.gaussian_blur_3d(torch.from_numpy(x), st, "cpu")
+            out[f"y_{si}_{ti}"] = y.numpy()
+    save("blur", **out)
+
+
+def g_zoom(R):
+    rng = np.random.default_rng(31)
+    out = {}
+    cases = [((3, 3, 2, 3), (24, 20, 16)), ((5, 5, 5), (48, 48, 48)), ((40, 40, 40), (48, 48, 48)),
+             ((1, 2, 1), (32, 32, 32)), ((20, 17, 29), (32, 32, 32)), ((9, 8, 7, 3), (40, 36, 28))]
+    out["ncases"] = np.int64(len(cases))
+    for i, (s, d) in enumerate(cases):
+        x = rng.standard_normal(s).astype(np.float32)
+        factor = np.array(d) / np.array(s[:3])
+        y = R.gen.myzoom_torch(torch.from_numpy(x), factor)
+        out[f"x_{i}"] = x
+        out[f"factor_{i}"] = factor
+        out[f"y_{i}"] = y.numpy()
+    save("zoom", **out)
+
+
+def g_interp(R):
+    rng = np.random.default_rng(41)
+    out = {}
+    for ci, shape in enumerate([(16, 16, 16), (12, 10, 8)]):
+        x = (rng.random(shape, dtype=np.float32) * 255).astype(np.float32)
+        npts = (9, 8, 7)
+        hi = np.array(shape, dtype=np.float32) - 1
+        c = (rng.random((3,) + npts, dtype=np.float32) * (hi[:, None, None, None] + 2) - 1).astype(np.float32)
+        flat = c.reshape(3, -1)
+        # engineered edge coordinates
+        flat[:, 0] = 0.0
+        flat[:, 1] = hi
+        flat[:, 2] = [2.5, 3.5, 4.5]
+        flat[:, 3] = [0.5, 1.5, 0.5]
+        flat[:, 4] = [-0.0, 1.0, 1.0]
+        flat[:, 5] = [1.0, 0.0, 1.0]
+        flat[:, 6] = [hi[0], 1.25, hi[2] - 0.5]
+        flat[:, 7] = np.nextafter(hi, np.float32(0))
+        flat[:, 8] = np.nextafter(np.float32(0), np.float32(1))
+        flat[:, 9] = [5.5, 6.5, 3.49999]
+        c = flat.reshape((3,) + npts)
+        cc = np.clip(c, 0, hi[:, None, None, None]).astype(np.float32)  # deform_image clamps first
+        for tag, co in (("raw", c), ("clamped", cc)):
+            II, JJ, KK = (torch.from_numpy(co[a].copy()) for a in range(3))
+            out[f"lin_{ci}_{tag}"] = R.gen.fast_3D_interp_torch(torch.from_numpy(x), II, JJ, KK, "linear").numpy()
+            out[f"nn_{ci}_{tag}"] = R.gen.fast_3D_interp_torch(torch.from_numpy(x), II, JJ, KK, "nearest").numpy()
+            out[f"coords_{ci}_{tag}"] = co
+        out[f"x_{ci}"] = x
+    save("interp", **out)
+
+
+def g_deform_image(R):
+    rng = np.random.default_rng(51)
+    out = {}
+    cases = []
+    # (shape, size, rot, shear, scale, F?)
+    cases.append(((24, 20, 16), (24, 20, 16), (0.2, -0.1, 0.3), (0.01, -0.02, 0.015), (1.05, 0.95, 1.0), True))
+    cases.append(((32, 32, 32), (32, 32, 32), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.9, 0.9, 0.9), False))  # non-zero margins
+    cases.append(((20, 24, 28), (16, 16, 16), (-0.3, 0.25, 0.1), (0.0, 0.02, -0.01), (1.1, 1.0, 0.92), True))
+    out["ncases"] = np.int64(len(cases))
+    for i, (shape, size, rot, sh, sc, useF) in enumerate(cases):
+        sd = R.SpatialDeformation(20, 0.02, 0.1, list(size), 1.0, True, 0.03, 0.06, 4, 0.5, "cpu")
+        sd._prepare_grid(shape)
+        A = torch.tensor(R.gen.make_affine_matrix(np.array(rot), np.array(sh), np.array(sc)), dtype=torch.float)
+        c2 = torch.tensor((np.array(shape) - 1) / 2, dtype=torch.float) + torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64)
+        F = None
+        if useF:
+            fs = rng.standard_normal((4, 3, 5, 3)).astype(np.float32) * 2.0
+            F = R.gen.myzoom_torch(torch.from_numpy(fs), np.array(shape) / np.array(fs.shape[:3]))
+            out[f"Fsmall_{i}"] = fs
+        xx2, yy2, zz2, x1, y1, z1, x2, y2, z2 = sd.deform_image(shape, A, c2, F)
+        out[f"shape_{i}"] = np.array(shape)
+        out[f"size_{i}"] = np.array(size)
+        out[f"A_{i}"] = A.numpy()
+        out[f"c2_{i}"] = c2.numpy()
+        out[f"coords_{i}"] = np.stack([xx2.numpy(), yy2.numpy(), zz2.numpy()])
+        out[f"margins_{i}"] = np.array([x1, y1, z1, x2, y2, z2]).astype(np.int64)
+    save("deform_image", **out)
+
+
+DEFAULT_SEED_LABELS = [0] + list(range(10, 50))
+DEFAULT_GEN_CLASSES = [0] + [10] * 10 + [20] * 10 + [30] * 10 + list(range(40, 50))
+
+
+def g_gmm(R):
+    rng = np.random.default_rng(61)
+    labs = np.array([0, 10, 11, 20, 30, 31, 32, 40, 49])
+    seeds = labs[rng.integers(0, len(labs), (16, 16, 16))].astype(np.int64)
+    out = {"seeds": seeds.astype(np.uint8)}
+    for k, gc in enumerate([DEFAULT_GEN_CLASSES, DEFAULT_SEED_LABELS]):
+        ifs = R.ImageFromSeeds(1, 6, DEFAULT_SEED_LABELS, gc)
+        torch.manual_seed(0)
+        with Tape() as tape:
+            img, p = ifs.sample_intensities(torch.from_numpy(seeds), "cpu")
+        out[f"img_{k}"] = img.numpy()
+        out[f"mus_{k}"] = p["mus"].numpy()
+        out[f"sigmas_{k}"] = p["sigmas"].numpy()
+        out.update(tape.pack(f"tape{k}"))
+    # fixed genparams
+    ifs = R.ImageFromSeeds(1, 6, DEFAULT_SEED_LABELS, DEFAULT_GEN_CLASSES)
+    torch.manual_seed(3)
+    mus = 25 + 200 * torch.rand(50)
+    sig = 5 + 20 * torch.rand(50)
+    out["fixed_mus_in"] = mus.numpy().copy()
+    out["fixed_sigmas_in"] = sig.numpy().copy()
+    torch.manual_seed(4)
+    img, p = ifs.sample_intensities(torch.from_numpy(seeds), "cpu", genparams={"mus": mus, "sigmas": sig})
+    out["fixed_img"] = img.numpy()
+    out["fixed_mus_out"] = p["mus"].numpy()
+    save("gmm", **out)
+
+
+def g_stages(R):
+    """RandGamma / RandBiasField / RandResample / RandNoise / resize_back on 32^3."""
+    rng = np.random.default_rng(71)
+    x = (rng.random((32, 32, 32), dtype=np.float32) * 255).astype(np.float32)
+    x[:4] = 0.0
+    out = {"x": x}
+    for seed in range(3):
+        for gates in ("on", "off"):
+            p = 1.0 if gates == "on" else 0.0
+            gam = R.RandGamma(p, 0.1)
+            bf = R.RandBiasField(p, 0.05, 0.2, 0.01, 0.3)
+            rs = R.RandResample(p, 0.5, 1.5)
+            nz = R.RandNoise(p, 5, 15)
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            key = f"s{seed}_{gates}"
+            with Tape() as tape:
+                a, pa = gam(torch.from_numpy(x), "cpu")
+                b, pb = bf(a, "cpu")
+                c, factors, pc = rs(b, np.array([0.5, 0.5, 0.5]), "cpu")
+                d, pd = nz(c, "cpu")
+                e = rs.resize_back(d, factors)
+            out[f"{key}_gamma"] = a.numpy()
+            out[f"{key}_bias"] = b.numpy()
+            out[f"{key}_resampled"] = c.numpy()
+            out[f"{key}_noisy"] = d.numpy()
+            out[f"{key}_back"] = e.numpy()
+            if gates == "on":
+                out[f"{key}_p_gamma"] = np.float64(pa["gamma"])
+                out[f"{key}_p_bf_scale"] = np.asarray(pb["bf_scale"], dtype=np.float64)
+                out[f"{key}_p_bf_std"] = np.asarray(pb["bf_std"], dtype=np.float64)
+                out[f"{key}_p_bf_size"] = np.asarray(pb["bf_size"], dtype=np.int64)
+                out[f"{key}_p_spacing"] = np.asarray(pc["spacing"], dtype=np.float64)
+                out[f"{key}_p_factors"] = np.asarray(factors, dtype=np.float64)
+                out[f"{key}_p_noise_std"] = np.float64(pd["noise_std"])
+            out.update(tape.pack(f"{key}_tape"))
+    # anisotropic fixed spacing through genparams (only some axes blurred)
+    rs = R.RandResample(0.0, 0.5, 1.5)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    c, factors, pc = rs(torch.from_numpy(x), np.array([0.5, 0.5, 0.5]), "cpu", genparams={"spacing": [0.5, 0.8, 1.3]})
+    out["aniso_resampled"] = c.numpy()
+    out["aniso_factors"] = np.asarray(factors)
+    out["aniso_back"] = rs.resize_back(c, factors).numpy()
+    save("stages", **out)
+
+
+class _Recorder:
+    """Wraps a callable stage object and stores its first return value."""
+
+    def __init__(self, inner, store, key):
+        self.__dict__["_inner"] = inner
+        self.__dict__["_store"] = store
+        self.__dict__["_key"] = key
+
+    def __call__(self, *a, **k):
+        r = self._inner(*a, **k)
+        self._store[self._key] = r[0].detach().clone()
+        return r
+
+    def __getattr__(self, n):
+        return getattr(self._inner, n)
+
+
+def build_generator(R, shape, prob=1.0, nonlin=(0.03, 0.06), size=None, bf_scale=(0.004, 0.02),
+                    res=(0.5, 0.5, 0.5), rmin=0.5, rmax=1.5):
+    size = list(shape) if size is None else list(size)
+    return R.FetalSynthGen(
+        shape=list(shape), resolution=list(res), device="cpu",
+        intensity_generator=R.ImageFromSeeds(1, 6, DEFAULT_SEED_LABELS, DEFAULT_GEN_CLASSES),
+        spatial_deform=R.SpatialDeformation(20, 0.02, 0.1, size, prob, True, nonlin[0], nonlin[1], 4, 0.5, "cpu"),
+        resampler=R.RandResample(prob, rmin, rmax),
+        bias_field=R.RandBiasField(prob, bf_scale[0], bf_scale[1], 0.01, 0.3),
+        noise=R.RandNoise(prob, 5, 15),
+        gamma=R.RandGamma(prob, 0.1),
+    )
+
+
+def run_e2e(R, shape, seed, variant=0, keep_stages=True, **gen_kw):
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    seg, seeds = make_seed_volumes(shape, variant)
+    table = {}
+    paths = {}
+    for n_sub, d in seeds.items():
+        paths[n_sub] = {}
+        for m, vol in d.items():
+            key = f"seed_{n_sub}_{m}"
+            table[key] = torch.from_numpy(vol.copy())
+            paths[n_sub][m] = key
+    gen = build_generator(R, shape, **gen_kw)
+    gen.intensity_generator.loader = lambda p: table[p].clone()
+    stages = {}
+    ig = gen.intensity_generator
+    orig_si = ig.sample_intensities
+
+    def si(*a, **k):
+        r = orig_si(*a, **k)
+        stages["gmm"] = r[0].detach().clone()
+        return r
+
+    ig.sample_intensities = si
+    sd = gen.spatial_deform
+    orig_g = sd.generate_deformation_and_flip
+
+    def gd(*a, **k):
+        r = orig_g(*a, **k)
+        if r[0] is not None:
+            stages["coords"] = torch.stack([r[0], r[1], r[2]]).detach().clone()
+        return r
+
+    sd.generate_deformation_and_flip = gd
+    orig_a = sd.apply_deformation_and_flip
+
+    def ad(*a, **k):
+        r = orig_a(*a, **k)
+        stages["warped"] = r[2].detach().clone()
+        return r
+
+    sd.apply_deformation_and_flip = ad
+    gen.gamma = _Recorder(gen.gamma, stages, "gamma")
+    gen.biasfield = _Recorder(gen.biasfield, stages, "bias")
+    gen.noise = _Recorder(gen.noise, stages, "noisy")
+    gen.resampled = _Recorder(gen.resampled, stages, "resampled")
+
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    with Tape() as tape:
+        out, seg_out, _img, params = gen.sample(image=None, segmentation=torch.from_numpy(seg), seeds=paths)
+    scaled = sys.modules["monai.transforms"].ScaleIntensity(0, 1)(out)
+    res = {
+        "shape": np.array(shape), "seed": np.int64(seed), "variant": np.int64(variant),
+        "out": out.numpy(), "seg_out": seg_out.numpy().astype(np.uint8), "scaled": scaled.numpy(),
+        "mus": params["seed_intensities"]["mus"].numpy(), "sigmas": params["seed_intensities"]["sigmas"].numpy(),
+        "mlabel2subclusters": np.array([params["selected_seeds"]["mlabel2subclusters"][m] for m in range(1, 5)]),
+        "flip": np.bool_(params["deform_params"]["flip"]),
+    }
+    assert np.array_equal(seg_out.numpy(), seg_out.numpy().astype(np.uint8))
+    dp = params["deform_params"]
+    if dp["affine"] is not None:
+        res["rotations"] = np.asarray(dp["affine"]["rotations"])
+        res["shears"] = np.asarray(dp["affine"]["shears"])
+        res["scalings"] = np.asarray(dp["affine"]["scalings"])
+        res["nonlin_scale"] = np.asarray(dp["non_rigid"]["nonlin_scale"], dtype=np.float64)
+        res["nonlin_std"] = np.float64(dp["non_rigid"]["nonlin_std"])
+        res["size_F_small"] = np.asarray(dp["non_rigid"]["size_F_small"])
+    g = params["gamma_params"]["gamma"]
+    res["gamma"] = np.float64(np.nan if g is None else g)
+    sp = params["resample_params"]["spacing"]
+    res["spacing"] = np.asarray([np.nan] * 3 if sp is None else sp, dtype=np.float64)
+    ns = params["noise_params"]["noise_std"]
+    res["noise_std"] = np.float64(np.nan if ns is None else ns)
+    if params["bf_params"]["bf_size"] is not None:
+        res["bf_size"] = np.asarray(params["bf_params"]["bf_size"])
+        res["bf_std"] = np.asarray(params["bf_params"]["bf_std"], dtype=np.float64)
+    if keep_stages:
+        for k, v in stages.items():
+            res["stage_" + k] = v.numpy()
+    res.update(tape.pack("tape"))
+    return res
+
+
+def g_e2e(R):
+    save("e2e_32_s0", **run_e2e(R, (32, 32, 32), 0))
+    save("e2e_32_s1", **run_e2e(R, (32, 32, 32), 1, nonlin=(0.1, 0.3), bf_scale=(0.05, 0.2)))
+    save("e2e_32_s2", **run_e2e(R, (32, 32, 32), 2, prob=0.5))
+    save("e2e_48_s0", **run_e2e(R, (48, 48, 48), 0, keep_stages=False, nonlin=(0.08, 0.2)))
+    save("e2e_nc_s1", **run_e2e(R, (40, 36, 28), 1, keep_stages=False, nonlin=(0.1, 0.2), variant=3))
+    save("e2e_sz_s4", **run_e2e(R, (40, 40, 40), 4, keep_stages=False, nonlin=(0.1, 0.2), size=(32, 32, 32)))
+
+
+def g_config1(R, ref):
+    """BASELINE config 1: sub-sta21 decimated to 128^3, CPU reference, seed 0 (summary stats)."""
+    data = Path(ref) / "data"
+    seg, _ = read_nifti(data / "sub-sta21/anat/sub-sta21_rec-irtk_T2w_dseg.nii.gz")
+    seg = np.ascontiguousarray(seg[::2, ::2, ::2]).astype(np.float32)
+    table, paths = {}, {}
+    for n_sub in range(1, 7):
+        paths[n_sub] = {}
+        for m in range(1, 5):
+            p = data / f"derivatives/seeds/subclasses_{n_sub}/sub-sta21/anat/sub-sta21_rec-irtk_T2w_dseg_mlabel_{m}.nii.gz"
+            paths[n_sub][m] = str(p)
+    loaded = {}
+
+    def loader(p):
+        if p not in loaded:
+            v, _ = read_nifti(p)
+            loaded[p] = torch.from_numpy(np.ascontiguousarray(v[::2, ::2, ::2]))
+        return loaded[p].clone()
+
+    gen = build_generator(R, (128, 128, 128), prob=0.9, res=(1.0, 1.0, 1.0), rmin=1.0, rmax=3.0)
+    gen.intensity_generator.loader = loader
+    np.random.seed(0)
+    torch.manual_seed(0)
+    with Tape() as tape:
+        out, seg_out, _img, params = gen.sample(image=None, segmentation=torch.from_numpy(seg), seeds=paths)
+    scaled = sys.modules["monai.transforms"].ScaleIntensity(0, 1)(out).numpy()
+    so = seg_out.numpy().astype(np.uint8)
+    m2s = params["selected_seeds"]["mlabel2subclusters"]
+    comb = sum(loaded[paths[m2s[m]][m]].numpy().astype(np.int16) for m in range(1, 5)).astype(np.uint8)
+    res = {
+        "seg_in": seg.astype(np.uint8), "seeds_in": comb,
+        "mlabel2subclusters": np.array([m2s[m] for m in range(1, 5)]),
+        "stats": np.array([scaled.min(), scaled.max(), scaled.mean(dtype=np.float64), scaled.std(dtype=np.float64)]),
+        "label_counts": np.bincount(so.reshape(-1), minlength=8),
+        "slice_x": scaled[64].astype(np.float16), "slice_y": scaled[:, 64].astype(np.float16),
+        "slice_z": scaled[:, :, 64].astype(np.float16),
+        "seg_slice_x": so[64], "seg_slice_y": so[:, 64], "seg_slice_z": so[:, :, 64],
+        "sub8": scaled[::8, ::8, ::8].copy(), "seg_sub4": so[::4, ::4, ::4].copy(),
+    }
+    res.update(tape.pack("tape"))
+    save("config1_sta21_128", **res)
+
+
+ALL = {
+    "affine": g_affine, "gauss": g_gauss, "blur": g_blur, "zoom": g_zoom, "interp": g_interp,
+    "deform_image": g_deform_image, "gmm": g_gmm, "stages": g_stages, "e2e": g_e2e,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    install_stubs()
+    sys.path.insert(0, args.ref)
+    R = types.SimpleNamespace()
+    import fetalsyngen.utils.generation as gen
+    from fetalsyngen.generator.deformation.affine_nonrigid import SpatialDeformation
+    from fetalsyngen.generator.intensity.rand_gmm import ImageFromSeeds
+    from fetalsyngen.generator.augmentation.synthseg import RandGamma, RandBiasField, RandResample, RandNoise
+    from fetalsyngen.generator.model import FetalSynthGen
+
+    R.gen, R.SpatialDeformation, R.ImageFromSeeds = gen, SpatialDeformation, ImageFromSeeds
+    R.RandGamma, R.RandBiasField, R.RandResample, R.RandNoise = RandGamma, RandBiasField, RandResample, RandNoise
+    R.FetalSynthGen = FetalSynthGen
+    torch.set_num_threads(8)
+    for name, fn in ALL.items():
+        if args.only and name != args.only:
+            continue
+        print(name)
+        fn(R)
+    if not args.only or args.only == "config1":
+        print("config1")
+        g_config1(R, args.ref)
+
+
+if __name__ == "__main__":
+    main()
