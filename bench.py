@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-volume synthesis hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full pass of the path (GMM draw -> deformation min/max -> fused warp(+gamma+bias,
+labels) -> 3-pass Gaussian blur -> resample+noise -> zoom-back+[0,1] normalise) over one synthetic
+256^3 label volume that is already resident in HBM (uint8 seed labels + fp32 segmentation), every
+stage gate on, device-Philox RNG, outputs left in HBM.  N > 1: one process per GPU (launched by
+torch.distributed.run), every rank processes its own volumes (independent work, no collective in the
+data path; gloo is used for the barrier and the max-over-ranks time only).
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable copy
+
+
+def build_generator(shape, device, rng_mode):
+    from fetalsyngen_amd.generator.augmentation.synthseg import RandBiasField, RandGamma, RandNoise, RandResample
+    from fetalsyngen_amd.generator.deformation.affine_nonrigid import SpatialDeformation
+    from fetalsyngen_amd.generator.intensity.rand_gmm import ImageFromSeeds
+    from fetalsyngen_amd.generator.model import FetalSynthGen
+
+    labels = [0] + list(range(10, 50))
+    classes = [0] + [10] * 10 + [20] * 10 + [30] * 10 + list(range(40, 50))
+    p = 1.0  # every gate on, so every kernel of the path runs in every step
+    return FetalSynthGen(
+        shape=list(shape), resolution=[0.5, 0.5, 0.5], device=device,
+        intensity_generator=ImageFromSeeds(1, 6, labels, classes),
+        spatial_deform=SpatialDeformation(20, 0.02, 0.1, list(shape), p, True, 0.03, 0.06, 4, 0.5, device),
+        resampler=RandResample(p, 0.5, 1.5), bias_field=RandBiasField(p, 0.004, 0.02, 0.01, 0.3),
+        noise=RandNoise(p, 5, 15), gamma=RandGamma(p, 0.1), rng=rng_mode)
+
+
+def blur_microbench(shape, device, sigma=1.3, reps=20):
+    """Back-to-back launches of each axis pass between HIP events; algorithmic bytes = 8 B/voxel/pass."""
+    from fetalsyngen_amd import kernels as K
+    from fetalsyngen_amd import tables as T
+
+    taps = T.gaussian_taps(sigma)
+    nvox = int(np.prod(shape))
+    out = {}
+    # L3-warm: same 64 MiB buffer re-read; L3-cold: cycle through > 256 MiB of distinct buffers
+    bufs = [torch.rand(shape, device=device) * 255 for _ in range(6)]
+    for label, pool in (("l3_warm", bufs[:1]), ("l3_cold", bufs)):
+        res = {}
+        for axis in range(3):
+            for w in range(3):
+                K.blur_axis(pool[w % len(pool)], axis, taps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for r in range(reps):
+                K.blur_axis(pool[r % len(pool)], axis, taps)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            res[f"axis{axis}"] = {"us": round(us, 2), "GBps": round(8.0 * nvox / us / 1e3, 1)}
+        out[label] = res
+    return out
+
+
+def cpu_baseline(shape, threads):
+    """The CPU restatement of the reference path (oracle/, validated against the real reference by the
+    golden vectors) timed on this host: one warm-up + one timed full-size sample."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+    from oracle import fsg_oracle as O
+
+    torch.set_num_threads(threads)
+    seg, seeds = make_seed_volumes(shape)
+    cfg = O.Config(shape, prob=1.0)
+    seg_t = torch.from_numpy(seg)
+    times = []
+    for rep in range(2):
+        np.random.seed(rep)
+        torch.manual_seed(rep)
+        t0 = time.perf_counter()
+        O.run_sample(cfg, seg_t, seeds)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(1.0 / times[-1], 4), "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"1 warm-up + 1 timed {shape[0]}^3 volume, all gates on, torch CPU ops ({times[-1]:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--rng", default="device", choices=["device", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
+    device = f"cuda:{local}"
+    torch.cuda.set_device(device)
+    shape = (args.size,) * 3
+    nvox = int(np.prod(shape))
+
+    # inputs resident in HBM before the timed region: 4 distinct label volumes per rank
+    banks, segs = [], []
+    for v in range(4):
+        seg, seeds = make_seed_volumes(shape, variant=rank * 4 + v)
+        banks.append(SeedBank(seeds, device))
+        segs.append(torch.from_numpy(seg).to(device))
+    gen = build_generator(shape, device, args.rng)
+
+    blur_ms = []
+
+    def step(i, timed):
+        sharding.seed_for_sample(1234, rank + world * i)
+        k = i % 4
+        out, seg_d, _img, _p = gen._pipeline(None, segs[k], banks[k], {}, scale01=True)
+        return out, seg_d
+
+    # per-step blur timing: HIP events (torch's current stream is the launch stream) around the 3 passes
+    from fetalsyngen_amd.generator.augmentation import synthseg as _ss
+
+    orig_blur = _ss.RandResample.blur
+    ev = []
+
+    def timed_blur(output, stds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_blur(output, stds)
+        e1.record()
+        ev.append((e0, e1, int(sum(1 for s in stds if s > 0))))
+        return r
+
+    _ss.RandResample.blur = staticmethod(timed_blur)
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    ev.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    _ss.RandResample.blur = staticmethod(orig_blur)
+
+    launches = sum(n for _, _, n in ev)
+    blur_total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    blur_us = blur_total_ms * 1e3 / max(launches, 1)
+    achieved = 8.0 * nvox / blur_us / 1e3 if launches else 0.0  # GB/s, algorithmic 8 B/voxel/pass
+
+    result = {
+        "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
+        "value": round(world * args.steps / dt, 3),
+        "unit": "volumes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: single {args.size}^3 label volume per step, full path, all gates on",
+                   "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation resident in HBM",
+                   "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
+                   "parallelism": f"{world} independent replicas (no collective)"},
+        "roofline": {"bound": "hbm", "kernel": "blur axis pass (fsg_blur_axis_taps_host_f32)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "us_per_launch": round(blur_us, 2), "launches_timed": launches,
+                     "algorithmic_bytes_per_launch": 8 * nvox},
+    }
+    if rank == 0:
+        if not args.no_microbench:
+            result["blur_microbench"] = blur_microbench(shape, device)
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            result["cpu_baseline"] = cpu_baseline(shape, threads)
+            result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""Build recipe for libfsg_hip.so (hipcc, gfx950 only, in-tree so it travels with `gpurun`)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libfsg_hip.so"
+SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libfsg_hip.so cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "fsg_common.h", PKG.parent / "include" / "fsg_hip.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objs = []
+    build_dir = PKG / "build"
+    build_dir.mkdir(exist_ok=True)
+    for s in SOURCES:
+        o = build_dir / (s + ".o")
+        cmd = [cc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(str(o))
+    tmp = LIB.with_suffix(".so.tmp")
+    subprocess.run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", str(tmp)], check=True)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,113 @@
+"""ctypes binding of libfsg_hip.so (C ABI in include/fsg_hip.h).
+
+There is NO fallback: if the library is missing or does not load, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libfsg_hip.so"
+
+E_BADARG, E_TOOBIG, E_ALIGN = -1, -2, -3
+
+
+class FsgError(RuntimeError):
+    def __init__(self, code: int, where: str, msg: str):
+        super().__init__(f"{where}: {msg} (code {code})")
+        self.code = code
+
+
+class Tap(C.Structure):
+    _fields_ = [("lo", C.c_int32), ("hi", C.c_int32), ("w_lo", C.c_float), ("w_hi", C.c_float)]
+
+
+class Deform(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int32 * 3),
+        ("A", C.c_float * 9),
+        ("centre", C.c_float * 3),
+        ("c2", C.c_float * 3),
+        ("flip", C.c_int32),
+        ("field_dims", C.c_int32 * 3),
+        ("field", C.c_void_p),
+        ("tx", C.c_void_p),
+        ("ty", C.c_void_p),
+        ("tz", C.c_void_p),
+    ]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_float),
+        ("bias_dims", C.c_int32 * 3),
+        ("bias", C.c_void_p),
+        ("bx", C.c_void_p),
+        ("by", C.c_void_p),
+        ("bz", C.c_void_p),
+    ]
+
+
+P, I, F, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> argtypes; every function returns int except where noted.  Must list EVERY symbol the
+# header declares (tests/test_abi.py cross-checks against include/fsg_hip.h).
+SIGNATURES = {
+    "fsg_abi_version": [],
+    "fsg_randn_f32": [P, SZ, U64, U64, P],
+    "fsg_gmm_sample_u8": [P, SZ, P, P, I, P, U64, U64, P, P],
+    "fsg_gmm_sample_i64": [P, SZ, P, P, I, P, U64, U64, P, P],
+    "fsg_label_stats_u8": [P, P, SZ, I, P, P, P, P],
+    "fsg_zoom3d_f32": [P, I, I, I, I, P, P, P, P, I, I, I, P],
+    "fsg_resample_noise_f32": [P, I, I, I, P, P, P, P, I, I, I, I, P, U64, U64, F, P],
+    "fsg_zoom3d_minmax_f32": [P, I, I, I, P, P, P, I, I, I, P, P],
+    "fsg_zoom3d_normalise_f32": [P, I, I, I, P, P, P, P, I, I, I, P, I, P],
+    "fsg_minmax_init": [P, I, I, P],
+    "fsg_coords_minmax_f32": [C.POINTER(Deform), P, P],
+    "fsg_coords_f32": [C.POINTER(Deform), P, P, P, P, P],
+    "fsg_warp_f32": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
+    "fsg_warp_f32_u8": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
+    "fsg_interp3d_f32": [P, I, I, I, P, P, P, SZ, I, F, P, P],
+    "fsg_gamma_f32": [P, SZ, F, P, P],
+    "fsg_bias_mul_f32": [P, I, I, I, P, I, I, I, P, P, P, P, P],
+    "fsg_blur_axis_f32": [P, P, I, I, I, I, P, I, P],
+    "fsg_blur_axis_taps_host_f32": [P, P, I, I, I, I, C.POINTER(C.c_float), I, P],
+    "fsg_add_noise_f32": [P, SZ, P, U64, U64, F, P, P],
+    "fsg_reduce_minmax_f32": [P, SZ, P, P],
+    "fsg_scale_f32": [P, SZ, P, I, P, P],
+}
+SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32])}
+
+_lib = None
+
+
+def load():
+    """dlopen libfsg_hip.so and declare prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). fetalsyngen_amd has no CPU or PyTorch fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (res, args) in SPECIAL_RESTYPE.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    if lib.fsg_abi_version() != 1:
+        raise RuntimeError("libfsg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, where: str):
+    if code != 0:
+        msg = load().fsg_error_string(code)
+        raise FsgError(code, where, msg.decode() if msg else "?")

@@ -1,0 +1,205 @@
+// fsg_blur.hip -- K6: one axis pass of the separable Gaussian blur.
+//
+// Replaces one `conv3d` call of `gaussian_blur_3d` (utils/generation.py:84-110): 1-D taps along one
+// axis, zero padding, no border renormalisation.  Algorithmic traffic: 4 B read + 4 B written per voxel
+// per pass; taps and halos are cache/LDS traffic.
+//
+// Round-1 kernels:
+//   blur_generic_kernel : any shape/alignment, one thread per voxel (correctness fallback).
+//   blur_strided_v4     : axis 0 / 1 (stride = inner floats), inner % 4 == 0: each lane owns a float4
+//                         column segment and produces TL consecutive outputs along the blur axis from
+//                         TL + 2R coalesced row loads (register sliding window, fully unrolled).
+//   blur_contig_lds     : axis 2 (z, contiguous): rows staged in LDS with zero halos, each lane produces
+//                         4 consecutive outputs from aligned ds_read_b128 windows.
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 129;  // radius <= 64 (sigma <= 21)
+
+struct Taps { float w[MAX_TAPS]; };
+
+// ---- generic ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blur_generic_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int outer, int len, int inner,
+                                                           const float* __restrict__ taps, int ntaps) {
+  // volume viewed as (outer, len, inner); blur along `len`
+  const size_t total = (size_t)outer * len * inner;
+  const int R = ntaps >> 1;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t in = e % inner;
+    const size_t rest = e / inner;
+    const int l = (int)(rest % len);
+    const size_t o = rest / len;
+    const float* base = src + (o * len) * inner + in;
+    float acc = 0.f;
+    const int t0 = max(0, R - l), t1 = min(ntaps, len - l + R);
+    for (int t = t0; t < t1; ++t) acc = fmaf(taps[t], base[(size_t)(l + t - R) * inner], acc);
+    dst[e] = acc;
+  }
+}
+
+// ---- strided axes, float4 lanes, register window ----------------------------------------------
+// grid: x = inner/4 chunks of 64 lanes, y = ceil(len / TL), z = outer
+template <int R, int TL>
+__global__ __launch_bounds__(256) void blur_strided_v4(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                       int len, int inner4, Taps T) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // float4 column
+  if (c >= inner4) return;
+  const int l0 = blockIdx.y * TL;
+  const size_t slab = (size_t)blockIdx.z * len * inner4;
+  const float4* s = src + slab + c;
+  float4 acc[TL];
+#pragma unroll
+  for (int o = 0; o < TL; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < TL + 2 * R; ++t) {
+    const int l = l0 + t - R;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l >= 0 && l < len) v = s[(size_t)l * inner4];
+#pragma unroll
+    for (int o = 0; o < TL; ++o) {
+      const int tap = t - o;  // input l0+t-R contributes to output l0+o with tap index t-o
+      if (tap >= 0 && tap <= 2 * R) {
+        const float w = T.w[tap];
+        acc[o].x = fmaf(w, v.x, acc[o].x);
+        acc[o].y = fmaf(w, v.y, acc[o].y);
+        acc[o].z = fmaf(w, v.z, acc[o].z);
+        acc[o].w = fmaf(w, v.w, acc[o].w);
+      }
+    }
+  }
+  float4* d = dst + slab + c;
+#pragma unroll
+  for (int o = 0; o < TL; ++o)
+    if (l0 + o < len) d[(size_t)(l0 + o) * inner4] = acc[o];
+}
+
+// ---- contiguous axis: rows through LDS ----------------------------------------------------------
+// block = 256 threads = 4 waves; each wave owns one row at a time: stages the row (nz floats) into LDS
+// with RP zero floats either side (RP = R rounded up to 4), then every lane produces 4 outputs.
+template <int R>
+__global__ __launch_bounds__(256) void blur_contig_lds(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int rows, int nz, Taps T) {
+  constexpr int RP = (R + 3) & ~3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pitch = nz + 2 * RP;  // nz % 4 == 0 -> pitch % 4 == 0
+  float* row = lds + (size_t)wave * pitch;
+  const int nz4 = nz >> 2;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * nz);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)r * nz);
+    if (lane < RP / 4) {
+      reinterpret_cast<float4*>(row)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(row + RP + nz)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int q = lane; q < nz4; q += 64) reinterpret_cast<float4*>(row + RP)[q] = s4[q];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+    for (int q = lane; q < nz4; q += 64) {
+      // window [4q - RP, 4q + 4 + RP) in row coordinates == LDS floats [4q, 4q + 4 + 2RP)
+      float win[4 + 2 * RP];
+#pragma unroll
+      for (int u = 0; u < (4 + 2 * RP) / 4; ++u) {
+        const float4 t = reinterpret_cast<const float4*>(row)[q + u];
+        win[4 * u] = t.x; win[4 * u + 1] = t.y; win[4 * u + 2] = t.z; win[4 * u + 3] = t.w;
+      }
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t <= 2 * R; ++t) {
+        const float w = T.w[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(w, win[RP - R + e + t], o[e]);
+      }
+      d4[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int R>
+int launch_strided(const float* src, float* dst, int outer, int len, int inner, const Taps& T, hipStream_t st) {
+  constexpr int TL = 16;
+  const int inner4 = inner / 4;
+  dim3 block(256), grid((unsigned)((inner4 + 255) / 256), (unsigned)((len + TL - 1) / TL), (unsigned)outer);
+  hipLaunchKernelGGL((blur_strided_v4<R, TL>), grid, block, 0, st, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), len, inner4, T);
+  FSG_RETURN_LAUNCH();
+}
+
+template <int R>
+int launch_contig(const float* src, float* dst, int rows, int nz, const Taps& T, hipStream_t st) {
+  constexpr int RP = (R + 3) & ~3;
+  const size_t lds = (size_t)4 * (nz + 2 * RP) * sizeof(float);
+  int grid = (rows + 3) / 4;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL((blur_contig_lds<R>), dim3(grid), dim3(256), lds, st, src, dst, rows, nz, T);
+  FSG_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int fsg_blur_axis_f32(const float* src, float* dst, int nx, int ny, int nz, int axis, const float* taps,
+                                 int ntaps, void* stream) {
+  if (!src || !dst || src == dst || !taps) return FSG_E_BADARG;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || axis < 0 || axis > 2) return FSG_E_BADARG;
+  if (ntaps <= 0 || (ntaps & 1) == 0) return FSG_E_BADARG;
+  hipStream_t st = fsg_stream(stream);
+  int outer, len, inner;
+  if (axis == 0) { outer = 1; len = nx; inner = ny * nz; }
+  else if (axis == 1) { outer = nx; len = ny; inner = nz; }
+  else { outer = nx * ny; len = nz; inner = 1; }
+  const size_t total = (size_t)nx * ny * nz;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(blur_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, outer, len, inner, taps,
+                     ntaps);
+  FSG_RETURN_LAUNCH();
+}
+
+// Fast paths take the taps by value (host pointer): no device round trip, graph-capturable.
+extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx, int ny, int nz, int axis,
+                                           const float* taps_host, int ntaps, void* stream) {
+  if (!src || !dst || src == dst || !taps_host) return FSG_E_BADARG;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || axis < 0 || axis > 2) return FSG_E_BADARG;
+  if (ntaps <= 0 || (ntaps & 1) == 0 || ntaps > MAX_TAPS) return FSG_E_BADARG;
+  if ((size_t)nx * ny * nz > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  hipStream_t st = fsg_stream(stream);
+  const int R = ntaps >> 1;
+  Taps T;
+  for (int t = 0; t < MAX_TAPS; ++t) T.w[t] = t < ntaps ? taps_host[t] : 0.f;
+  const bool aligned = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  if (axis == 2) {
+    const int rows = nx * ny;
+    if (aligned && (nz & 3) == 0 && R >= 1 && R <= 8 && nz <= 4096) {
+      switch (R) {
+        case 1: return launch_contig<1>(src, dst, rows, nz, T, st);
+        case 2: return launch_contig<2>(src, dst, rows, nz, T, st);
+        case 3: return launch_contig<3>(src, dst, rows, nz, T, st);
+        case 4: return launch_contig<4>(src, dst, rows, nz, T, st);
+        case 5: return launch_contig<5>(src, dst, rows, nz, T, st);
+        case 6: return launch_contig<6>(src, dst, rows, nz, T, st);
+        case 7: return launch_contig<7>(src, dst, rows, nz, T, st);
+        case 8: return launch_contig<8>(src, dst, rows, nz, T, st);
+      }
+    }
+    return FSG_E_ALIGN;  // caller falls back to fsg_blur_axis_f32
+  }
+  int outer, len, inner;
+  if (axis == 0) { outer = 1; len = nx; inner = ny * nz; }
+  else { outer = nx; len = ny; inner = nz; }
+  if (aligned && (inner & 3) == 0 && R >= 1 && R <= 8) {
+    switch (R) {
+      case 1: return launch_strided<1>(src, dst, outer, len, inner, T, st);
+      case 2: return launch_strided<2>(src, dst, outer, len, inner, T, st);
+      case 3: return launch_strided<3>(src, dst, outer, len, inner, T, st);
+      case 4: return launch_strided<4>(src, dst, outer, len, inner, T, st);
+      case 5: return launch_strided<5>(src, dst, outer, len, inner, T, st);
+      case 6: return launch_strided<6>(src, dst, outer, len, inner, T, st);
+      case 7: return launch_strided<7>(src, dst, outer, len, inner, T, st);
+      case 8: return launch_strided<8>(src, dst, outer, len, inner, T, st);
+    }
+  }
+  return FSG_E_ALIGN;
+}

@@ -1,0 +1,172 @@
+// fsg_common.h -- device helpers shared by the gfx950 kernels of libfsg_hip.so.
+// CDNA4 only: wave = 64 lanes, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fsg_hip.h"
+
+// The reference evaluates every interpolation as separate fp32 multiplies and adds (ATen CPU
+// element-wise ops).  Contraction to FMA would change sampling positions by 1 ulp and flip
+// nearest-neighbour labels, so it is off for the whole library; the blur asks for fmaf explicitly.
+#pragma clang fp contract(off)
+
+#define FSG_WAVE 64
+
+#define FSG_RETURN_LAUNCH()                 \
+  do {                                      \
+    hipError_t e_ = hipGetLastError();      \
+    return (int)e_;                         \
+  } while (0)
+
+static inline hipStream_t fsg_stream(void* s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------------------------
+// order-preserving float <-> int32 keys (so integer atomicMin/atomicMax reduce floats, -0 < +0)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int32_t fsg_f2key(float f) {
+  int32_t b = __builtin_bit_cast(int32_t, f);
+  return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__host__ __device__ __forceinline__ float fsg_key2f(int32_t k) {
+  int32_t b = k >= 0 ? k : (k ^ 0x7FFFFFFF);
+  return __builtin_bit_cast(float, b);
+}
+
+// wave-level min / max (64 lanes) by butterfly shuffles
+__device__ __forceinline__ float fsg_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, FSG_WAVE));
+  return v;
+}
+__device__ __forceinline__ float fsg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, FSG_WAVE));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: element e of stream (seed, stream_id) is lane e%4 of block e/4
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 fsg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                   uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
+    uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += W0; k1 += W1;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// four standard normals for counter block `blk`
+__device__ __forceinline__ float4 fsg_randn4(uint64_t seed, uint64_t stream_id, uint64_t blk) {
+  uint4 r = fsg_philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)stream_id,
+                              (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float S = 5.9604644775390625e-08f;  // 2^-24
+  float u0 = (float)((r.x >> 8) + 1u) * S;  // (0, 1]
+  float u1 = (float)((r.z >> 8) + 1u) * S;
+  float t0 = (float)(r.y >> 8) * S;         // [0, 1) revolutions
+  float t1 = (float)(r.w >> 8) * S;
+  // -2 ln u = -2 ln2 * log2 u ; v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 (input in revolutions)
+  float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  float4 z;
+  z.x = r0 * __builtin_amdgcn_cosf(t0);
+  z.y = r0 * __builtin_amdgcn_sinf(t0);
+  z.z = r1 * __builtin_amdgcn_cosf(t1);
+  z.w = r1 * __builtin_amdgcn_sinf(t1);
+  return z;
+}
+__device__ __forceinline__ float fsg_randn1(uint64_t seed, uint64_t stream_id, uint64_t e) {
+  float4 z = fsg_randn4(seed, stream_id, e >> 2);
+  switch ((int)(e & 3)) {
+    case 0: return z.x;
+    case 1: return z.y;
+    case 2: return z.z;
+    default: return z.w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// separable linear interpolation from a small/any grid with per-axis tables, reference order:
+//   x: t = wl*a + wh*b (per y,z corner), then y, then z   (utils/generation.py:376-386)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fsg_mix(float wl, float a, float wh, float b) { return wl * a + wh * b; }
+
+template <int NCH>
+__device__ __forceinline__ float fsg_tab_interp(const float* __restrict__ src, int sy, int sz, int ch,
+                                                const fsg_tap& a, const fsg_tap& b, const fsg_tap& c) {
+  const size_t rx0 = (size_t)a.lo * sy, rx1 = (size_t)a.hi * sy;
+  const float* p00 = src + ((rx0 + b.lo) * sz) * NCH + ch;
+  const float* p01 = src + ((rx0 + b.hi) * sz) * NCH + ch;
+  const float* p10 = src + ((rx1 + b.lo) * sz) * NCH + ch;
+  const float* p11 = src + ((rx1 + b.hi) * sz) * NCH + ch;
+  const int z0 = c.lo * NCH, z1 = c.hi * NCH;
+  float t00 = fsg_mix(a.w_lo, p00[z0], a.w_hi, p10[z0]);  // y = b.lo, z = c.lo
+  float t10 = fsg_mix(a.w_lo, p01[z0], a.w_hi, p11[z0]);  // y = b.hi, z = c.lo
+  float t01 = fsg_mix(a.w_lo, p00[z1], a.w_hi, p10[z1]);  // y = b.lo, z = c.hi
+  float t11 = fsg_mix(a.w_lo, p01[z1], a.w_hi, p11[z1]);  // y = b.hi, z = c.hi
+  float u0 = fsg_mix(b.w_lo, t00, b.w_hi, t10);
+  float u1 = fsg_mix(b.w_lo, t01, b.w_hi, t11);
+  return fsg_mix(c.w_lo, u0, c.w_hi, u1);
+}
+
+// kernel-argument copy of fsg_deform
+struct FsgDeformK {
+  int n0, n1, n2;
+  float A[9];
+  float cen[3];
+  float c2[3];
+  int flip;
+  int f0, f1, f2;
+  const float* field;
+  const fsg_tap* tx;
+  const fsg_tap* ty;
+  const fsg_tap* tz;
+};
+
+// clamped, un-shifted sampling position of grid point (i,j,k)  (affine_nonrigid.py:331-347)
+__device__ __forceinline__ void fsg_position(const FsgDeformK& D, int i, int j, int k, float& x, float& y, float& z) {
+  float px = (float)i - D.cen[0], py = (float)j - D.cen[1], pz = (float)k - D.cen[2];
+  if (D.field) {
+    const fsg_tap a = D.tx[i], b = D.ty[j], c = D.tz[k];
+    px = px + fsg_tab_interp<3>(D.field, D.f1, D.f2, 0, a, b, c);
+    py = py + fsg_tab_interp<3>(D.field, D.f1, D.f2, 1, a, b, c);
+    pz = pz + fsg_tab_interp<3>(D.field, D.f1, D.f2, 2, a, b, c);
+  }
+  x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
+  y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
+  z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  if (x < 0.f) x = 0.f;
+  if (y < 0.f) y = 0.f;
+  if (z < 0.f) z = 0.f;
+  if (x > hx) x = hx;
+  if (y > hy) y = hy;
+  if (z > hz) z = hz;
+}
+
+static inline int fsg_fill_deform(const fsg_deform* d, FsgDeformK& K) {
+  if (!d) return FSG_E_BADARG;
+  K.n0 = d->shape[0]; K.n1 = d->shape[1]; K.n2 = d->shape[2];
+  if (K.n0 <= 0 || K.n1 <= 0 || K.n2 <= 0) return FSG_E_BADARG;
+  if ((size_t)K.n0 * K.n1 * K.n2 > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  for (int t = 0; t < 9; ++t) K.A[t] = d->A[t];
+  for (int t = 0; t < 3; ++t) { K.cen[t] = d->centre[t]; K.c2[t] = d->c2[t]; }
+  K.flip = d->flip;
+  K.f0 = d->field_dims[0]; K.f1 = d->field_dims[1]; K.f2 = d->field_dims[2];
+  const bool has = K.f0 > 0 && K.f1 > 0 && K.f2 > 0;
+  K.field = has ? d->field : nullptr;
+  K.tx = d->tx; K.ty = d->ty; K.tz = d->tz;
+  if (has && (!d->field || !d->tx || !d->ty || !d->tz)) return FSG_E_BADARG;
+  return 0;
+}
+
+// launch geometry: x = 64 lanes along z, y = 4 rows along y; grid (z chunks, y chunks, x)
+static inline dim3 fsg_block3() { return dim3(64, 4, 1); }
+static inline dim3 fsg_grid3(int n0, int n1, int n2) {
+  return dim3((unsigned)((n2 + 63) / 64), (unsigned)((n1 + 3) / 4), (unsigned)n0);
+}

@@ -1,0 +1,196 @@
+"""Dataset boundary: mirror of `fetalsyngen.data.datasets.FetalSynthDataset`
+(reference datasets.py:189-370; base-class file discovery :17-103).
+
+Same constructor, `__len__`, `__getitem__`, `sample`, `sample_with_meta`, same output dict
+(`image` float32 (1,H,W,D) on the CPU in [0,1], `label` int64 (1,H,W,D) on the CPU, `name`), same
+`generation_params` keys, same `FileNotFoundError` / `RuntimeError` on missing / ambiguous files.
+
+MI355X-side additions (opt-in, defaults keep the reference's contract):
+  * decoded label volumes are cached on the device as uint8 (`SeedBank`) -- the reference re-reads
+    and gunzips five NIfTI files per sample;
+  * `return_device=True` keeps outputs on the GPU (uint8 labels) for device-side consumers;
+  * `ShardedSynthStream` partitions a sample-index range over ranks (one process per GPU).
+"""
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..generator.model import FetalSynthGen
+from ..utils.image_reading import NiftiReader
+
+
+class SeedBank:
+    """Per-subject decoded seed volumes, device resident (uint8), combined on demand."""
+
+    def __init__(self, volumes: dict, device):
+        self.device = device
+        self.vol = {
+            n: {m: torch.as_tensor(np.asarray(v)).to(torch.uint8).to(device) for m, v in d.items()}
+            for n, d in volumes.items()
+        }
+        self._cache = {}
+
+    def combined(self, mlabel2subclusters: dict) -> torch.Tensor:
+        key = tuple(sorted(mlabel2subclusters.items()))
+        hit = self._cache.get(key)
+        if hit is None:
+            hit = None
+            for m, n in mlabel2subclusters.items():
+                v = self.vol[n][m]
+                hit = v.clone() if hit is None else hit + v  # disjoint supports: values stay < 50
+            if len(self._cache) >= 8:
+                self._cache.pop(next(iter(self._cache)))
+            self._cache[key] = hit
+        return hit
+
+
+class FetalDataset:
+    """Subject / session discovery in a BIDS tree."""
+
+    def __init__(self, bids_path: str, sub_list: list[str] | None):
+        self.bids_path = Path(bids_path)
+        found = sorted(p.name for p in self.bids_path.glob("sub-*"))
+        self.subjects = found if sub_list is None else [s for s in found if s in set(sub_list)]
+        self.sub_ses = [(s, ses) for s in self.subjects for ses in self._get_ses(self.bids_path, s)]
+        self.loader = NiftiReader()
+        self.img_paths = self._load_bids_path(self.bids_path, "T2w")
+        self.segm_paths = self._load_bids_path(self.bids_path, "dseg")
+
+    @staticmethod
+    def _sub_ses_string(sub, ses):
+        return sub if ses is None else f"{sub}_{ses}"
+
+    def _sub_ses_idx(self, idx):
+        return self._sub_ses_string(*self.sub_ses[idx])
+
+    @staticmethod
+    def _get_ses(bids_path, sub):
+        names = [d.name for d in (bids_path / sub).iterdir() if d.is_dir()]
+        return sorted([None if "anat" in n else n for n in names], key=lambda x: x or "")
+
+    @staticmethod
+    def _get_pattern(sub, ses, suffix, extension=".nii.gz"):
+        if ses is None:
+            return f"{sub}/anat/{sub}*_{suffix}{extension}"
+        return f"{sub}/{ses}/anat/{sub}_{ses}*_{suffix}{extension}"
+
+    def _load_bids_path(self, path, suffix):
+        out = []
+        for sub, ses in self.sub_ses:
+            pattern = self._get_pattern(sub, ses, suffix)
+            files = list(Path(path).glob(pattern))
+            if not files:
+                raise FileNotFoundError(
+                    f"No files found for requested subject {sub} in {path} ({pattern} returned nothing)")
+            if len(files) > 1:
+                raise RuntimeError(
+                    f"Multiple files found for requested subject {sub} in {path} ({pattern} returned {files})")
+            out.append(files[0])
+        return out
+
+    def __len__(self):
+        return len(self.subjects)
+
+    def __getitem__(self, idx):
+        raise NotImplementedError("This method should be implemented in the child class.")
+
+
+class FetalSynthDataset(FetalDataset):
+    def __init__(
+        self,
+        bids_path: str,
+        generator: FetalSynthGen,
+        seed_path: str | None,
+        sub_list: list[str] | None,
+        load_image: bool = False,
+        image_as_intensity: bool = False,
+        cache_on_device: bool = True,
+        return_device: bool = False,
+    ):
+        super().__init__(bids_path, sub_list)
+        self.seed_path = Path(seed_path) if isinstance(seed_path, str) else None
+        self.load_image = load_image
+        self.generator = generator
+        self.image_as_intensity = image_as_intensity
+        self.cache_on_device = cache_on_device
+        self.return_device = return_device
+        self._banks, self._segs = {}, {}
+        if not self.image_as_intensity and isinstance(self.seed_path, Path):
+            if not self.seed_path.exists():
+                raise FileNotFoundError(f"Provided seed path {self.seed_path} does not exist.")
+            self._load_seed_path()
+
+    def _load_seed_path(self):
+        self.seed_paths = {self._sub_ses_string(s, ses): defaultdict(dict) for s, ses in self.sub_ses}
+        avail = [int(p.name.replace("subclasses_", "")) for p in self.seed_path.glob("subclasses_*")]
+        for n_sub in range(min(avail), max(avail) + 1):
+            folder = self.seed_path / f"subclasses_{n_sub}"
+            if not folder.exists():
+                raise FileNotFoundError(f"Provided seed path {folder} does not exist.")
+            for m in range(1, 5):
+                files = self._load_bids_path(folder, f"mlabel_{m}")
+                for (s, ses), f in zip(self.sub_ses, files):
+                    self.seed_paths[self._sub_ses_string(s, ses)][n_sub][m] = f
+
+    def _seeds_for(self, name):
+        if not self.cache_on_device:
+            return self.seed_paths[name]
+        if name not in self._banks:
+            vols = {n: {m: self.loader(p).numpy() for m, p in d.items()} for n, d in self.seed_paths[name].items()}
+            self._banks[name] = SeedBank(vols, self.generator.device)
+        return self._banks[name]
+
+    def _segmentation(self, idx):
+        if not self.cache_on_device:
+            return self.loader(self.segm_paths[idx])
+        if idx not in self._segs:
+            self._segs[idx] = self.loader(self.segm_paths[idx]).float().to(self.generator.device)
+        return self._segs[idx]
+
+    def sample(self, idx, genparams: dict = {}):
+        image = self.loader(self.img_paths[idx]).float() if self.load_image else None
+        segm = self._segmentation(idx)
+        name = self._sub_ses_idx(idx)
+        seeds = None
+        if self.seed_path is not None:
+            seeds = self._seeds_for(name)
+        if self.image_as_intensity:
+            seeds = None
+        generation_params = {
+            "idx": idx,
+            "img_paths": str(self.img_paths[idx]),
+            "segm_paths": str(self.img_paths[idx]),  # sic: the reference logs the image path here (ref :301)
+            "seeds": str(self.seed_path),
+        }
+        t0 = time.time()
+        gen_output, segmentation, image, synth_params = self.generator._pipeline(
+            image, segm, seeds, genparams, scale01=True)
+        if image is not None:
+            from .. import kernels as K
+
+            image = K.scale(image.contiguous(), K.reduce_minmax(image.contiguous()), mode=1)
+        if self.return_device:
+            label = segmentation if segmentation.dtype == torch.uint8 else segmentation.to(torch.uint8)
+        else:
+            gen_output = gen_output.cpu()
+            label = segmentation.cpu().long()
+            image = image.cpu() if image is not None else None
+        generation_params = {**generation_params, **synth_params}
+        generation_params["generation_time"] = time.time() - t0
+        data_out = {"image": gen_output.unsqueeze(0), "label": label.unsqueeze(0), "name": name}
+        return data_out, generation_params
+
+    def __getitem__(self, idx) -> dict:
+        data_out, generation_params = self.sample(idx)
+        self.generation_params = generation_params
+        return data_out
+
+    def sample_with_meta(self, idx: int, genparams: dict = {}) -> dict:
+        data, generation_params = self.sample(idx, genparams=genparams)
+        data["generation_params"] = generation_params
+        return data

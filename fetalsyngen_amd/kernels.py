@@ -1,0 +1,344 @@
+"""Torch-tensor front-end of the C ABI: pointer/shape plumbing only, no arithmetic.
+
+Every function validates device / dtype / contiguity on the host (a faulting kernel can take the whole
+node down), launches on torch's current HIP stream and returns freshly allocated device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tables import Arena, TAP_DTYPE
+
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError(
+                "fetalsyngen_amd kernels run on an MI355X (device='cuda:N') only; there is no CPU fallback"
+            )
+        if not t.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != F32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t
+
+
+def _dims3(t):
+    if t.dim() != 3:
+        raise ValueError(f"expected a 3-D volume, got shape {tuple(t.shape)}")
+    return int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
+
+
+class DeviceTables:
+    """Three per-axis tap tables resident on the device (one upload)."""
+
+    def __init__(self, tabs, device, arena: Arena | None = None):
+        own = arena is None
+        arena = arena or Arena()
+        self.lengths = tuple(len(t) for t in tabs)
+        for t in tabs:
+            if t.dtype != TAP_DTYPE:
+                raise TypeError("tap table dtype")
+        self._offs = [arena.add(t) for t in tabs]
+        self._arena = arena
+        if own:
+            arena.upload(device)
+
+    @property
+    def ptrs(self):
+        return tuple(C.c_void_p(self._arena.ptr(o)) for o in self._offs)
+
+
+def new_minmax(device, nmin=1, nmax=1):
+    mm = torch.empty(nmin + nmax, dtype=torch.int32, device=device)
+    _lib.check(_lib.load().fsg_minmax_init(_p(mm), nmin, nmax, _stream()), "fsg_minmax_init")
+    return mm
+
+
+def key_to_float(key: int) -> float:
+    return float(_lib.load().fsg_key_to_float(int(key)))
+
+
+# ---- RNG / K1 ---------------------------------------------------------------------------------
+def randn(shape, seed: int, stream_id: int, device) -> torch.Tensor:
+    out = torch.empty(tuple(shape), dtype=F32, device=device)
+    _need_gpu(out)
+    _lib.check(_lib.load().fsg_randn_f32(_p(out), out.numel(), seed, stream_id, _stream()), "fsg_randn_f32")
+    return out
+
+
+def gmm_sample(labels, mus, sigmas, noise=None, seed=0, stream_id=0) -> torch.Tensor:
+    _need_gpu(labels, mus, sigmas, noise)
+    _f32(mus), _f32(sigmas)
+    ntab = int(mus.numel())
+    if sigmas.numel() != ntab or not (0 < ntab <= 256):
+        raise ValueError("mus/sigmas must have the same length in 1..256")
+    if noise is not None and (_f32(noise).numel() != labels.numel()):
+        raise ValueError("noise must match labels")
+    out = torch.empty(labels.shape, dtype=F32, device=labels.device)
+    lib = _lib.load()
+    if labels.dtype == torch.uint8:
+        fn, name = lib.fsg_gmm_sample_u8, "fsg_gmm_sample_u8"
+    elif labels.dtype == torch.int64:
+        fn, name = lib.fsg_gmm_sample_i64, "fsg_gmm_sample_i64"
+    else:
+        raise TypeError("labels must be uint8 or int64")
+    _lib.check(fn(_p(labels), labels.numel(), _p(mus), _p(sigmas), ntab, _p(noise), seed, stream_id, _p(out),
+                  _stream()), name)
+    return out
+
+
+def label_stats(labels_u8, values, nlabels: int):
+    """(count int64[nlabels], mean f64, var f64) per label -- wave-level reductions on the device."""
+    _need_gpu(labels_u8, values)
+    if labels_u8.dtype != torch.uint8 or labels_u8.numel() != _f32(values).numel():
+        raise TypeError("labels uint8 and values float32 of equal size expected")
+    dev = values.device
+    cnt = torch.zeros(nlabels, dtype=torch.int64, device=dev)
+    s1 = torch.zeros(nlabels, dtype=torch.float64, device=dev)
+    s2 = torch.zeros(nlabels, dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().fsg_label_stats_u8(_p(labels_u8), _p(values), values.numel(), nlabels, _p(cnt), _p(s1),
+                                              _p(s2), _stream()), "fsg_label_stats_u8")
+    n = cnt.clamp(min=1).double()
+    mean = s1 / n
+    return cnt, mean, s2 / n - mean * mean
+
+
+# ---- zoom family --------------------------------------------------------------------------------
+def _zoom_args(src, tabs: DeviceTables, nch=1):
+    _need_gpu(src)
+    _f32(src)
+    if nch == 1:
+        sx, sy, sz = _dims3(src)
+    else:
+        if src.dim() != 4 or src.shape[3] != nch:
+            raise ValueError("channel-last 4-D source expected")
+        sx, sy, sz = (int(v) for v in src.shape[:3])
+    return sx, sy, sz
+
+
+def zoom3d(src, tabs: DeviceTables) -> torch.Tensor:
+    nch = 1 if src.dim() == 3 else int(src.shape[3])
+    if nch not in (1, 3):
+        raise ValueError("1 or 3 channels supported")
+    sx, sy, sz = _zoom_args(src, tabs, nch)
+    dx, dy, dz = tabs.lengths
+    shape = (dx, dy, dz) if nch == 1 else (dx, dy, dz, nch)
+    dst = torch.empty(shape, dtype=F32, device=src.device)
+    tx, ty, tz = tabs.ptrs
+    _lib.check(_lib.load().fsg_zoom3d_f32(_p(src), sx, sy, sz, nch, tx, ty, tz, _p(dst), dx, dy, dz, _stream()),
+               "fsg_zoom3d_f32")
+    return dst
+
+
+def resample_noise(src, tabs: DeviceTables, noise_std=0.0, noise=None, seed=None, stream_id=0) -> torch.Tensor:
+    sx, sy, sz = _zoom_args(src, tabs)
+    dx, dy, dz = tabs.lengths
+    dst = torch.empty((dx, dy, dz), dtype=F32, device=src.device)
+    mode = 0
+    if noise is not None:
+        _need_gpu(noise)
+        if _f32(noise).numel() != dst.numel():
+            raise ValueError("noise size")
+        mode = 1
+    elif seed is not None:
+        mode = 2
+    tx, ty, tz = tabs.ptrs
+    _lib.check(_lib.load().fsg_resample_noise_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz, mode,
+                                                  _p(noise), seed or 0, stream_id, float(noise_std), _stream()),
+               "fsg_resample_noise_f32")
+    return dst
+
+
+def zoom_minmax(src, tabs: DeviceTables) -> torch.Tensor:
+    sx, sy, sz = _zoom_args(src, tabs)
+    dx, dy, dz = tabs.lengths
+    mm = new_minmax(src.device)
+    tx, ty, tz = tabs.ptrs
+    _lib.check(_lib.load().fsg_zoom3d_minmax_f32(_p(src), sx, sy, sz, tx, ty, tz, dx, dy, dz, _p(mm), _stream()),
+               "fsg_zoom3d_minmax_f32")
+    return mm
+
+
+def zoom_normalise(src, tabs: DeviceTables, mm, mode: int) -> torch.Tensor:
+    sx, sy, sz = _zoom_args(src, tabs)
+    _need_gpu(mm)
+    dx, dy, dz = tabs.lengths
+    dst = torch.empty((dx, dy, dz), dtype=F32, device=src.device)
+    tx, ty, tz = tabs.ptrs
+    _lib.check(_lib.load().fsg_zoom3d_normalise_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz, _p(mm),
+                                                    mode, _stream()), "fsg_zoom3d_normalise_f32")
+    return dst
+
+
+# ---- deformation ----------------------------------------------------------------------------------
+class DeformSpec:
+    """Host-side description of one spatial deformation + its device-resident small arrays."""
+
+    def __init__(self, shape, A32, centre32, c2_32, flip, field_small=None, field_tabs=None, device=None):
+        self.shape = tuple(int(v) for v in shape)
+        self.device = device
+        d = _lib.Deform()
+        d.shape[:] = self.shape
+        d.A[:] = [float(v) for v in np.asarray(A32, dtype=np.float32).reshape(-1)]
+        d.centre[:] = [float(v) for v in np.asarray(centre32, dtype=np.float32)]
+        d.c2[:] = [float(v) for v in np.asarray(c2_32, dtype=np.float32)]
+        d.flip = int(bool(flip))
+        self._keep = []
+        if field_small is not None:
+            _need_gpu(field_small)
+            _f32(field_small)
+            if field_small.dim() != 4 or field_small.shape[3] != 3:
+                raise ValueError("coarse field must be (s0,s1,s2,3)")
+            if field_tabs.lengths != self.shape:
+                raise ValueError("field tables must have the grid's lengths")
+            d.field_dims[:] = [int(v) for v in field_small.shape[:3]]
+            d.field = field_small.data_ptr()
+            tx, ty, tz = field_tabs.ptrs
+            d.tx, d.ty, d.tz = tx.value, ty.value, tz.value
+            self._keep += [field_small, field_tabs]
+        else:
+            d.field_dims[:] = [0, 0, 0]
+        self.c = d
+
+
+def coords_minmax(spec: DeformSpec) -> torch.Tensor:
+    mm6 = new_minmax(spec.device, 3, 3)
+    _lib.check(_lib.load().fsg_coords_minmax_f32(C.byref(spec.c), _p(mm6), _stream()), "fsg_coords_minmax_f32")
+    return mm6
+
+
+def coords(spec: DeformSpec, mm6):
+    out = [torch.empty(spec.shape, dtype=F32, device=spec.device) for _ in range(3)]
+    _lib.check(_lib.load().fsg_coords_f32(C.byref(spec.c), _p(mm6), _p(out[0]), _p(out[1]), _p(out[2]), _stream()),
+               "fsg_coords_f32")
+    return out
+
+
+def warp(spec: DeformSpec, mm6, src_lin=None, src_nn=None, gamma=None, bias=None, bias_tabs=None):
+    """Fused warp: returns (out_lin | None, out_nn | None)."""
+    _need_gpu(mm6, src_lin, src_nn, bias)
+    for s in (src_lin, src_nn):
+        if s is not None and tuple(s.shape) != spec.shape:
+            raise ValueError(f"volume shape {tuple(s.shape)} != grid {spec.shape}")
+    out_lin = torch.empty_like(_f32(src_lin)) if src_lin is not None else None
+    out_nn = torch.empty_like(src_nn) if src_nn is not None else None
+    epi = _lib.Epilogue()
+    epi.gamma = float(np.float32(gamma)) if gamma is not None else 0.0
+    if bias is not None:
+        _f32(bias)
+        if bias_tabs.lengths != spec.shape:
+            raise ValueError("bias tables must have the grid's lengths")
+        epi.bias_dims[:] = _dims3(bias)
+        epi.bias = bias.data_ptr()
+        bx, by, bz = bias_tabs.ptrs
+        epi.bx, epi.by, epi.bz = bx.value, by.value, bz.value
+    lib = _lib.load()
+    if src_nn is None or src_nn.dtype == F32:
+        fn, name = lib.fsg_warp_f32, "fsg_warp_f32"
+    elif src_nn.dtype == torch.uint8:
+        fn, name = lib.fsg_warp_f32_u8, "fsg_warp_f32_u8"
+    else:
+        raise TypeError("nearest-neighbour volume must be float32 or uint8")
+    _lib.check(fn(C.byref(spec.c), _p(mm6), _p(src_lin), _p(out_lin), _p(src_nn), _p(out_nn), C.byref(epi), _stream()),
+               name)
+    return out_lin, out_nn
+
+
+def interp3d(src, ii, jj, kk, mode: str, default_value=0.0) -> torch.Tensor:
+    _need_gpu(src, ii, jj, kk)
+    sx, sy, sz = _dims3(_f32(src))
+    if not (ii.shape == jj.shape == kk.shape):
+        raise ValueError("coordinate shapes differ")
+    for c in (ii, jj, kk):
+        _f32(c)
+    if mode not in ("linear", "nearest"):
+        raise Exception("mode must be linear or nearest")
+    dst = torch.empty(ii.shape, dtype=F32, device=src.device)
+    _lib.check(_lib.load().fsg_interp3d_f32(_p(src), sx, sy, sz, _p(ii), _p(jj), _p(kk), ii.numel(),
+                                            1 if mode == "nearest" else 0, float(default_value), _p(dst), _stream()),
+               "fsg_interp3d_f32")
+    return dst
+
+
+# ---- pointwise / blur / reductions ------------------------------------------------------------
+def gamma(x, g: float) -> torch.Tensor:
+    _need_gpu(x)
+    out = torch.empty_like(_f32(x))
+    _lib.check(_lib.load().fsg_gamma_f32(_p(x), x.numel(), float(np.float32(g)), _p(out), _stream()), "fsg_gamma_f32")
+    return out
+
+
+def bias_mul(x, bias, bias_tabs: DeviceTables) -> torch.Tensor:
+    _need_gpu(x, bias)
+    nx, ny, nz = _dims3(_f32(x))
+    b0, b1, b2 = _dims3(_f32(bias))
+    if bias_tabs.lengths != (nx, ny, nz):
+        raise ValueError("bias tables must have the volume's lengths")
+    out = torch.empty_like(x)
+    bx, by, bz = bias_tabs.ptrs
+    _lib.check(_lib.load().fsg_bias_mul_f32(_p(x), nx, ny, nz, _p(bias), b0, b1, b2, bx, by, bz, _p(out), _stream()),
+               "fsg_bias_mul_f32")
+    return out
+
+
+def add_noise(x, noise_std: float, noise=None, seed=0, stream_id=0) -> torch.Tensor:
+    _need_gpu(x, noise)
+    out = torch.empty_like(_f32(x))
+    if noise is not None and _f32(noise).numel() != x.numel():
+        raise ValueError("noise size")
+    _lib.check(_lib.load().fsg_add_noise_f32(_p(x), x.numel(), _p(noise), seed, stream_id, float(noise_std), _p(out),
+                                             _stream()), "fsg_add_noise_f32")
+    return out
+
+
+def blur_axis(x, axis: int, taps: np.ndarray, force_generic=False) -> torch.Tensor:
+    _need_gpu(x)
+    nx, ny, nz = _dims3(_f32(x))
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    if taps.ndim != 1 or len(taps) % 2 == 0:
+        raise ValueError("odd number of taps expected")
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    rc = _lib.E_ALIGN
+    if not force_generic and len(taps) <= 129:
+        rc = lib.fsg_blur_axis_taps_host_f32(_p(x), _p(out), nx, ny, nz, axis,
+                                             taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps), _stream())
+    if rc == _lib.E_ALIGN:  # shape not covered by the tuned kernels -> generic kernel (still HIP)
+        tdev = torch.from_numpy(taps).to(x.device)
+        rc = lib.fsg_blur_axis_f32(_p(x), _p(out), nx, ny, nz, axis, _p(tdev), len(taps), _stream())
+    _lib.check(rc, "fsg_blur_axis")
+    return out
+
+
+def reduce_minmax(x) -> torch.Tensor:
+    _need_gpu(x)
+    mm = new_minmax(x.device)
+    _lib.check(_lib.load().fsg_reduce_minmax_f32(_p(_f32(x)), x.numel(), _p(mm), _stream()), "fsg_reduce_minmax_f32")
+    return mm
+
+
+def scale(x, mm, mode: int) -> torch.Tensor:
+    _need_gpu(x, mm)
+    out = torch.empty_like(_f32(x))
+    _lib.check(_lib.load().fsg_scale_f32(_p(x), x.numel(), _p(mm), mode, _p(out), _stream()), "fsg_scale_f32")
+    return out

@@ -1,0 +1,74 @@
+"""Where the two large Gaussian fields of a sample come from.
+
+The reference draws them with `torch.randn(shape, device=device)` from the global generator of
+`device` (rand_gmm.py:146-148, synthseg.py:230-232).  Two modes here:
+
+  "reference": draw with `torch.randn(shape)` from the CPU global generator at the same point of the
+               draw order and upload -- bit-identical noise to the reference's CPU path under the
+               same `torch.manual_seed`; costs a 4 B/voxel host draw + PCIe copy per field.
+  "device":    in-kernel Philox4x32-10; the 64-bit key of each field is taken from the CPU global
+               generator (so runs are still reproducible under `torch.manual_seed`), nothing else
+               touches the host.  `fsg_randn_f32` regenerates the identical field for checking.
+
+All SMALL draws (GMM tables, coarse displacement grid, bias grid, scalars) use numpy's / torch's CPU
+global generators with the reference's calls in the reference's order in both modes.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+
+import torch
+
+_MODE = os.environ.get("FSG_RNG", "device")
+_VALID = ("reference", "device")
+
+
+def get_mode() -> str:
+    return _MODE
+
+
+def set_mode(mode: str) -> None:
+    global _MODE
+    if mode not in _VALID:
+        raise ValueError(f"rng mode must be one of {_VALID}")
+    _MODE = mode
+
+
+@contextlib.contextmanager
+def use(mode: str | None):
+    global _MODE
+    if mode is None:
+        yield
+        return
+    prev = _MODE
+    set_mode(mode)
+    try:
+        yield
+    finally:
+        _MODE = prev
+
+
+class Field:
+    """A standard-normal field that is either host values or a Philox key."""
+
+    __slots__ = ("shape", "host", "seed", "stream_id")
+
+    def __init__(self, shape, host=None, seed=None, stream_id=0):
+        self.shape, self.host, self.seed, self.stream_id = tuple(shape), host, seed, stream_id
+
+    def device_tensor(self, device):
+        """Materialise on the device (only needed by the un-fused API paths and by tests)."""
+        from . import kernels as K
+
+        if self.host is not None:
+            h = self.host.pin_memory() if torch.cuda.is_available() else self.host
+            return h.to(device, non_blocking=True)
+        return K.randn(self.shape, self.seed, self.stream_id, device)
+
+
+def normal_field(shape, stream_id: int = 0) -> Field:
+    if _MODE == "reference":
+        return Field(shape, host=torch.randn(tuple(shape), dtype=torch.float32))
+    key = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    return Field(shape, seed=key, stream_id=stream_id)

@@ -1,0 +1,113 @@
+"""Host-side parameter preparation: per-axis sample tables, Gaussian taps, parameter arena.
+
+These are the few-hundred-byte to few-KB inputs of the kernels.  They are computed on the host with
+the same torch / numpy calls the reference uses for the same quantities, so the sample positions and
+weights the kernels consume are bit-identical to the reference's:
+
+  * zoom tables     -- utils/generation.py:315-363 (`torch.arange(..., dtype=float32)[:n]`, clamp, floor)
+  * resample tables -- generator/augmentation/synthseg.py:84-102 (float64 `np.arange`, cast to fp32) +
+                       the validity test / split of utils/generation.py:228-256
+  * Gaussian taps   -- utils/generation.py:74-81
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+TAP_DTYPE = np.dtype([("lo", "<i4"), ("hi", "<i4"), ("w_lo", "<f4"), ("w_hi", "<f4")])
+
+
+def _pack(lo, hi, w_lo, w_hi) -> np.ndarray:
+    t = np.empty(len(lo), dtype=TAP_DTYPE)
+    t["lo"], t["hi"], t["w_lo"], t["w_hi"] = lo, hi, w_lo, w_hi
+    return t
+
+
+def zoom_table(n_src: int, factor: float, n_dst: int) -> np.ndarray:
+    """One axis of the separable linear zoom: n_dst samples of an n_src-long axis."""
+    delta = (1.0 - factor) / (2.0 * factor)
+    pos = torch.arange(delta, delta + n_dst / factor, 1 / factor, dtype=torch.float32)[:n_dst]
+    pos = pos.clamp_(min=0).clamp_(max=n_src - 1)
+    lo = torch.floor(pos).to(torch.int32)
+    hi = torch.clamp(lo + 1, max=n_src - 1)
+    w_hi = pos - lo
+    w_lo = 1 - w_hi
+    return _pack(lo.numpy(), hi.numpy(), w_lo.numpy(), w_hi.numpy())
+
+
+def zoom_tables(src_shape, factor):
+    """(tables for x,y,z, destination shape) for `zoom(src, factor)`."""
+    factor = np.asarray(factor, dtype=np.float64)
+    new = np.round(np.asarray(src_shape[:3]) * factor).astype(int)
+    tabs = [zoom_table(int(src_shape[a]), float(factor[a]), int(new[a])) for a in range(3)]
+    return tabs, tuple(int(v) for v in new)
+
+
+def position_table(pos64: np.ndarray, n_src: int) -> np.ndarray:
+    """Table for explicit float64 sample positions along one axis (axis-aligned trilinear gather):
+    positions are rounded to fp32 first; outside (0, n_src-1] is marked lo = -1."""
+    p = torch.tensor(np.asarray(pos64), dtype=torch.float32)
+    ok = (p > 0) & (p <= n_src - 1)
+    lo = torch.floor(p).to(torch.int32)
+    hi = torch.clamp(lo + 1, max=n_src - 1)
+    w_hi = p - lo
+    w_lo = 1 - w_hi
+    lo = torch.where(ok, lo, torch.full_like(lo, -1))
+    hi = torch.where(ok, hi, torch.zeros_like(hi))
+    return _pack(lo.numpy(), hi.numpy(), w_lo.numpy(), w_hi.numpy())
+
+
+def resample_plan(in_shape, resolution, spacing, u_std: float):
+    """Blur sigmas, low-res size, factors and per-axis tables of RandResample."""
+    spacing = np.array(spacing, dtype=np.float64)
+    resolution = np.array(resolution, dtype=np.float64)
+    size = np.array(in_shape)
+    stds = (0.85 + 0.3 * u_std) * np.log(5) / np.pi * spacing / resolution
+    stds[spacing <= resolution] = 0.0
+    new_size = (size * resolution / spacing).astype(int)
+    factors = new_size / size
+    delta = (1.0 - factors) / (2.0 * factors)
+    tabs = []
+    for a in range(3):
+        pos = np.arange(delta[a], delta[a] + new_size[a] / factors[a], 1 / factors[a])[: new_size[a]]
+        tabs.append(position_table(pos, int(size[a])))
+    return stds, tuple(int(v) for v in new_size), factors, tabs
+
+
+def gaussian_taps(sigma: float) -> np.ndarray:
+    half = int(np.ceil(3 * sigma))
+    t = torch.linspace(-half, half, 2 * half + 1, dtype=torch.float32)
+    g = torch.exp(-((t / sigma) ** 2) / 2)
+    return (g / g.sum()).numpy()
+
+
+class Arena:
+    """Packs many small host arrays into ONE pinned buffer and uploads them with one async copy.
+
+    Pointers handed to the C ABI are `base + offset`.  The device tensor must stay alive until the
+    kernels that read it have been enqueued on the same stream (stream-ordered allocator semantics)."""
+
+    ALIGN = 256
+
+    def __init__(self):
+        self._items = []
+        self._size = 0
+
+    def add(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        off = self._size
+        self._items.append((off, arr))
+        self._size = (off + arr.nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        return off
+
+    def upload(self, device) -> torch.Tensor:
+        host = torch.empty(max(self._size, self.ALIGN), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        hv = host.numpy()
+        for off, arr in self._items:
+            hv[off : off + arr.nbytes] = arr.view(np.uint8).reshape(-1)
+        self.dev = host.to(device, non_blocking=True)
+        self.base = self.dev.data_ptr()
+        return self.dev
+
+    def ptr(self, off: int) -> int:
+        return self.base + off

@@ -317,8 +317,10 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
 
     seed_volumes[n_sub][mlabel] -> integer array (the decoded seed file).  `noise_gmm` /
     `noise_lowres`: when given, used INSTEAD of drawing the two large torch.randn fields
-    (device-RNG parity: the HIP path's Philox noise is injected here); `noise_lowres` may be
-    a callable (shape)->tensor because the low-res shape is only known mid-way.
+    (device-RNG parity: the HIP path's Philox noise is injected here); either may be a
+    callable (shape)->tensor, invoked at the point of the draw order where the field is
+    needed (the low-res shape is only known mid-way, and a callable may itself consume
+    the torch generator exactly like the product's key draw does).
     Returns dict(out, seg, scaled, params, stages)."""
     st = {}
     lo_s, hi_s = cfg.subclusters
@@ -336,7 +338,10 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     if cfg.generation_classes != cfg.seed_labels:
         z_cls = torch.randn(len(cfg.seed_labels), dtype=F32)
     mus, sigmas = gmm_tables(u_mu, u_sg, z_cls, cfg.seed_labels, cfg.generation_classes)
-    z = torch.randn(seeds.shape, dtype=F32) if noise_gmm is None else noise_gmm
+    if noise_gmm is None:
+        z = torch.randn(seeds.shape, dtype=F32)
+    else:
+        z = noise_gmm(tuple(seeds.shape)) if callable(noise_gmm) else noise_gmm
     out = gmm_image(seeds, mus, sigmas, z)
     st["gmm"] = out
 
