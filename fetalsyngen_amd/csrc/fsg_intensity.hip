@@ -146,8 +146,8 @@ inline unsigned grid_for(size_t items, unsigned cap = 4096) {
 template <typename LT>
 int launch_gmm(const LT* labels, size_t n, const float* mus, const float* sigmas, int ntab, const float* noise,
                uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+  if (n == 0) return 0;  // empty volume: nothing to do, pointers may be null
   if (!labels || !mus || !sigmas || !out || ntab <= 0 || ntab > 256) return FSG_E_BADARG;
-  if (n == 0) return 0;
   hipLaunchKernelGGL(gmm_kernel<LT>, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, fsg_stream(stream), labels, n,
                      mus, sigmas, ntab, noise, seed, stream_id, out);
   FSG_RETURN_LAUNCH();
