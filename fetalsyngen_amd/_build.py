@@ -10,6 +10,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libfsg_hip.so"
 SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip"]
+EXTRA = os.environ.get("FSG_EXTRA_FLAGS", "").split()
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -37,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     build_dir.mkdir(exist_ok=True)
     for s in SOURCES:
         o = build_dir / (s + ".o")
-        cmd = [cc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+        cmd = [cc, *FLAGS, *EXTRA, "-c", str(CSRC / s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -35,6 +35,8 @@ class Deform(C.Structure):
         ("tx", C.c_void_p),
         ("ty", C.c_void_p),
         ("tz", C.c_void_p),
+        ("rows", C.c_void_p),
+        ("row_stride", C.c_int32),
     ]
 
 
@@ -55,6 +57,7 @@ P, I, F, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 # header declares (tests/test_abi.py cross-checks against include/fsg_hip.h).
 SIGNATURES = {
     "fsg_abi_version": [],
+    "fsg_set_tuning": [I],
     "fsg_randn_f32": [P, SZ, U64, U64, P],
     "fsg_gmm_sample_u8": [P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_gmm_sample_i64": [P, SZ, P, P, I, P, U64, U64, P, P],
@@ -64,6 +67,7 @@ SIGNATURES = {
     "fsg_zoom3d_minmax_f32": [P, I, I, I, P, P, P, I, I, I, P, P],
     "fsg_zoom3d_normalise_f32": [P, I, I, I, P, P, P, P, I, I, I, P, I, P],
     "fsg_minmax_init": [P, I, I, P],
+    "fsg_deform_rows_f32": [C.POINTER(Deform), C.POINTER(Epilogue), P, I, P],
     "fsg_coords_minmax_f32": [C.POINTER(Deform), P, P],
     "fsg_coords_f32": [C.POINTER(Deform), P, P, P, P, P],
     "fsg_warp_f32": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],

@@ -12,6 +12,8 @@
 
 #define FSG_WAVE 64
 
+extern int g_tuning_flags;
+
 #define FSG_RETURN_LAUNCH()                 \
   do {                                      \
     hipError_t e_ = hipGetLastError();      \
@@ -30,6 +32,19 @@ __host__ __device__ __forceinline__ int32_t fsg_f2key(float f) {
 __host__ __device__ __forceinline__ float fsg_key2f(int32_t k) {
   int32_t b = k >= 0 ? k : (k ^ 0x7FFFFFFF);
   return __builtin_bit_cast(float, b);
+}
+
+// Global min / max of order keys.  The targets only ever move one way, so a (possibly stale) relaxed read
+// that already dominates the candidate proves the atomic is unnecessary: after the first few blocks almost
+// every block skips it (same-address atomics serialise at ~11 ns each and 2048 of them cost more than the
+// reduction itself).
+__device__ __forceinline__ void fsg_atomic_min_key(int32_t* p, float v) {
+  const int32_t k = fsg_f2key(v);
+  if (k < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, k);
+}
+__device__ __forceinline__ void fsg_atomic_max_key(int32_t* p, float v) {
+  const int32_t k = fsg_f2key(v);
+  if (k > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, k);
 }
 
 // wave-level min / max (64 lanes) by butterfly shuffles
@@ -126,6 +141,8 @@ struct FsgDeformK {
   const fsg_tap* tx;
   const fsg_tap* ty;
   const fsg_tap* tz;
+  const float* rows;  // optional: per-(i,j) x/y-interpolated coarse rows (fsg_deform_rows_f32), else null
+  int row_stride;
 };
 
 // clamped, un-shifted sampling position of grid point (i,j,k)  (affine_nonrigid.py:331-347)
@@ -162,6 +179,8 @@ static inline int fsg_fill_deform(const fsg_deform* d, FsgDeformK& K) {
   K.field = has ? d->field : nullptr;
   K.tx = d->tx; K.ty = d->ty; K.tz = d->tz;
   if (has && (!d->field || !d->tx || !d->ty || !d->tz)) return FSG_E_BADARG;
+  K.rows = d->rows; K.row_stride = d->row_stride;
+  if (K.rows && K.row_stride < 3 * K.f2) return FSG_E_BADARG;
   return 0;
 }
 

@@ -10,6 +10,8 @@
 // materialised: each thread re-evaluates the coarse field (<= 40 KB, L1/L2 resident) at its voxel.
 #include "fsg_common.h"
 
+int g_tuning_flags = 0;  // FSG_TUNE_* bits, see fsg_set_tuning
+
 namespace {
 
 struct Margins { float mx, my, mz; };
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(256) void coords_minmax_kernel(FsgDeformK D, int32_
     float v = red[a][0];
     for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[a][w]) : fmaxf(v, red[a][w]);
     // -0.0 must order below +0.0 like torch.min would see it only by sign; keys keep the sign bit
-    if (a < 3) atomicMin(&mm6[a], fsg_f2key(v));
-    else atomicMax(&mm6[a], fsg_f2key(v));
+    if (a < 3) fsg_atomic_min_key(&mm6[a], v);
+    else fsg_atomic_max_key(&mm6[a], v);
   }
 }
 
@@ -118,6 +120,427 @@ struct EpiK {
   const fsg_tap* bz;
 };
 
+// =================================================================================================
+// Row-wise kernels (the tuned path).  One wave owns one output row (i, j, all k) at a time:
+//   1. the 64 lanes evaluate the x- and y-interpolation of the coarse displacement grid (and of the
+//      coarse bias grid) ONCE per row -- 3*f2 + b2 values -- into a wave-private LDS slot;
+//   2. every voxel of the row then needs only the z-interpolation: two LDS reads + one lerp per
+//      channel, instead of 8 global loads + 7 lerps per channel.
+// The arithmetic per voxel is the same sequence of fp32 operations as fsg_tab_interp (x, then y, then
+// z; products then sum, no FMA), so positions are bit-identical to the per-voxel kernels.
+// =================================================================================================
+constexpr int ROWCAP = 512;  // floats of LDS per wave (3*f2 + b2 must fit; else per-voxel fallback)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// x/y part of the separable interpolation for one row: dst[c*s2 + zs], c < NCH
+template <int NCH>
+__device__ __forceinline__ void fill_row_xy(const float* __restrict__ grid, int s1, int s2, const fsg_tap a,
+                                            const fsg_tap b, float* dst, int lane) {
+  const float* p00 = grid + (((size_t)a.lo * s1 + b.lo) * s2) * NCH;
+  const float* p10 = grid + (((size_t)a.hi * s1 + b.lo) * s2) * NCH;
+  const float* p01 = grid + (((size_t)a.lo * s1 + b.hi) * s2) * NCH;
+  const float* p11 = grid + (((size_t)a.hi * s1 + b.hi) * s2) * NCH;
+  for (int e = lane; e < NCH * s2; e += FSG_WAVE) {
+    const int c = e / s2, zs = e - c * s2;
+    const int o = zs * NCH + c;
+    const float t0 = fsg_mix(a.w_lo, p00[o], a.w_hi, p10[o]);  // y = b.lo
+    const float t1 = fsg_mix(a.w_lo, p01[o], a.w_hi, p11[o]);  // y = b.hi
+    dst[e] = fsg_mix(b.w_lo, t0, b.w_hi, t1);
+  }
+}
+
+__device__ __forceinline__ fsg_tap uniform_tap(const fsg_tap* t, int idx) {
+  // idx is wave-uniform: broadcast through SGPRs so the 16-byte load is issued once
+  const int4 v = *reinterpret_cast<const int4*>(t + idx);
+  fsg_tap r;
+  r.lo = __builtin_amdgcn_readfirstlane(v.x);
+  r.hi = __builtin_amdgcn_readfirstlane(v.y);
+  r.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.z));
+  r.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.w));
+  return r;
+}
+
+// position of voxel (i,j,k) from the row's LDS slot (same op order as fsg_position)
+__device__ __forceinline__ void row_position(const FsgDeformK& D, const float* sm, int i, int j, int k,
+                                             const fsg_tap& c, float& x, float& y, float& z) {
+  float px = (float)i - D.cen[0], py = (float)j - D.cen[1], pz = (float)k - D.cen[2];
+  if (D.field) {
+    px = px + fsg_mix(c.w_lo, sm[c.lo], c.w_hi, sm[c.hi]);
+    py = py + fsg_mix(c.w_lo, sm[D.f2 + c.lo], c.w_hi, sm[D.f2 + c.hi]);
+    pz = pz + fsg_mix(c.w_lo, sm[2 * D.f2 + c.lo], c.w_hi, sm[2 * D.f2 + c.hi]);
+  }
+  x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
+  y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
+  z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  if (x < 0.f) x = 0.f;
+  if (y < 0.f) y = 0.f;
+  if (z < 0.f) z = 0.f;
+  if (x > hx) x = hx;
+  if (y > hy) y = hy;
+  if (z > hz) z = hz;
+}
+
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+// trilinear gather with the two z-neighbours fetched by one 8-byte load (needs n2 >= 2).
+// Same blend order as sample_linear; when z0 == n2-1 the ceil neighbour is clamped onto z0 as in the
+// reference (its weight is then exactly 0).
+__device__ __forceinline__ float sample_linear_pairs(const float* __restrict__ s, const FsgDeformK& D, float x,
+                                                     float y, float z) {
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f) && (x <= hx) && (y <= hy) && (z <= hz);
+  if (!ok) return 0.f;
+  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  int x1 = min(x0 + 1, D.n0 - 1);
+  const int y1 = min(y0 + 1, D.n1 - 1);
+  const float bx = x - fx, by = y - fy, bz = z - fz;
+  const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
+  int xs0 = x0, xs1 = x1;
+  if (D.flip) { xs0 = D.n0 - 1 - x0; xs1 = D.n0 - 1 - x1; }
+  const int zb = min(z0, D.n2 - 2);
+  const bool hi0 = z0 != zb;  // only when z0 == n2-1: both neighbours are the pair's upper element
+  const float* r00 = s + ((size_t)xs0 * D.n1 + y0) * D.n2 + zb;
+  const float* r10 = s + ((size_t)xs1 * D.n1 + y0) * D.n2 + zb;
+  const float* r01 = s + ((size_t)xs0 * D.n1 + y1) * D.n2 + zb;
+  const float* r11 = s + ((size_t)xs1 * D.n1 + y1) * D.n2 + zb;
+  const float2_u p00 = *reinterpret_cast<const float2_u*>(r00);
+  const float2_u p10 = *reinterpret_cast<const float2_u*>(r10);
+  const float2_u p01 = *reinterpret_cast<const float2_u*>(r01);
+  const float2_u p11 = *reinterpret_cast<const float2_u*>(r11);
+  const float c000 = hi0 ? p00.y : p00.x, c001 = p00.y;
+  const float c100 = hi0 ? p10.y : p10.x, c101 = p10.y;
+  const float c010 = hi0 ? p01.y : p01.x, c011 = p01.y;
+  const float c110 = hi0 ? p11.y : p11.x, c111 = p11.y;
+  const float c00 = c000 * ax + c100 * bx;
+  const float c01 = c001 * ax + c101 * bx;
+  const float c10 = c010 * ax + c110 * bx;
+  const float c11 = c011 * ax + c111 * bx;
+  const float c0 = c00 * ay + c10 * by;
+  const float c1 = c01 * ay + c11 * by;
+  return c0 * az + c1 * bz;
+}
+
+// logical tile id: hardware deals consecutive workgroups round-robin over the 8 XCDs; give every XCD a
+// contiguous range of tiles (= a slab of x planes) so the source planes it gathers from stay in ITS L2.
+// Speed only: any mapping gives the same result.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
+// ---- per-row coarse values, precomputed once per deformation ------------------------------------------
+// rows[(i*n1 + j)*stride + e]: e < 3*f2 -> x/y-interpolated displacement (channel-major, then z index of
+// the coarse grid); 3*f2 <= e < 3*f2 + b2 -> x/y-interpolated bias grid.  One thread per entry.  With this
+// buffer the warp / min-max kernels start a row with ONE coalesced load instead of a dependent chain
+// (table entry -> four coarse-grid loads -> LDS).
+__global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, float* __restrict__ rows, int stride) {
+  const int nf = D.field ? 3 * D.f2 : 0;
+  const int need = nf + (E.bias ? E.b2 : 0);
+  const size_t total = (size_t)D.n0 * D.n1 * need;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t % need);
+    const int r = (int)(t / need);
+    const int i = r / D.n1, j = r - i * D.n1;
+    float v;
+    if (e < nf) {
+      const fsg_tap a = D.tx[i], b = D.ty[j];
+      const int c = e / D.f2, zs = e - c * D.f2;
+      const int o = zs * 3 + c;
+      const float* g = D.field;
+      const float f00 = g[(((size_t)a.lo * D.f1 + b.lo) * D.f2) * 3 + o];
+      const float f10 = g[(((size_t)a.hi * D.f1 + b.lo) * D.f2) * 3 + o];
+      const float f01 = g[(((size_t)a.lo * D.f1 + b.hi) * D.f2) * 3 + o];
+      const float f11 = g[(((size_t)a.hi * D.f1 + b.hi) * D.f2) * 3 + o];
+      v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
+    } else {
+      const fsg_tap a = E.bx[i], b = E.by[j];
+      const int zs = e - nf;
+      const float* g = E.bias;
+      const float f00 = g[((size_t)a.lo * E.b1 + b.lo) * E.b2 + zs];
+      const float f10 = g[((size_t)a.hi * E.b1 + b.lo) * E.b2 + zs];
+      const float f01 = g[((size_t)a.lo * E.b1 + b.hi) * E.b2 + zs];
+      const float f11 = g[((size_t)a.hi * E.b1 + b.hi) * E.b2 + zs];
+      v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
+    }
+    rows[(size_t)r * stride + e] = v;
+  }
+}
+
+constexpr int WARP_ROWS_PER_WAVE = 4;
+
+// Four voxels of one lane (k = kbase + 64*q), branch-free: every address is in range by construction
+// (positions are clamped to [0, n-1] before the margin subtraction, which only lowers them towards 0), so
+// the 16 pair-gathers + 4 nearest gathers are issued back to back and their latencies overlap; the strict
+// ">0" validity rule of the reference is applied as a select afterwards.  Arithmetic per voxel is identical
+// to sample_linear / sample_nearest.
+// Tuning knobs measured on MI355X (tools/kernel_bench.py, 256^3, rot 12 deg): batch 2 + skipping the gathers
+// of voxels that sample outside the volume is the fastest of {1,2,4} x {skip, no skip} for the full kernel.
+#ifndef FSG_WARP_BATCH
+#define FSG_WARP_BATCH 2
+#endif
+#ifndef FSG_WARP_NO_SKIP_OUTSIDE
+#define FSG_WARP_SKIP_OUTSIDE 1
+#endif
+
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST, int Q0, int NQ>
+__device__ __forceinline__ void warp_emitN(const FsgDeformK& D, const EpiK& E, const Margins& m, const float* sm,
+                                           int nf, int i, int j, int kbase, const fsg_tap (&ck)[4],
+                                           const fsg_tap (&cbk)[4], size_t row, const float* __restrict__ src_lin,
+                                           float* __restrict__ out_lin, const LT* __restrict__ src_nn,
+                                           LT* __restrict__ out_nn) {
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  const unsigned sx = (unsigned)D.n1 * (unsigned)D.n2, sy = (unsigned)D.n2;
+  float x[NQ], y[NQ], z[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int k = min(kbase + 64 * (Q0 + q), D.n2 - 1);
+    row_position(D, sm, i, j, k, ck[Q0 + q], x[q], y[q], z[q]);
+    x[q] = x[q] - m.mx;
+    y[q] = y[q] - m.my;
+    z[q] = z[q] - m.mz;
+  }
+  LT nn[NQ];
+  if (HAS_NN) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      int xi = (int)rintf(x[q]), yi = (int)rintf(y[q]), zi = (int)rintf(z[q]);
+      xi = min(max(xi, 0), D.n0 - 1);
+      yi = min(max(yi, 0), D.n1 - 1);
+      zi = min(max(zi, 0), D.n2 - 1);
+      if (D.flip) xi = D.n0 - 1 - xi;
+      nn[q] = src_nn[(unsigned)xi * sx + (unsigned)yi * sy + (unsigned)zi];
+    }
+  }
+  float2_u p00[NQ], p10[NQ], p01[NQ], p11[NQ];
+  float bx[NQ], by[NQ], bz[NQ];
+  bool ok[NQ], hi0[NQ];
+  if (HAS_LIN) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      ok[q] = (x[q] > 0.f) && (y[q] > 0.f) && (z[q] > 0.f) && (x[q] <= hx) && (y[q] <= hy) && (z[q] <= hz);
+      const float fx = floorf(x[q]), fy = floorf(y[q]), fz = floorf(z[q]);
+      bx[q] = x[q] - fx;
+      by[q] = y[q] - fy;
+      bz[q] = z[q] - fz;
+      int x0 = min(max((int)fx, 0), D.n0 - 1), y0 = min(max((int)fy, 0), D.n1 - 1), z0 = min(max((int)fz, 0), D.n2 - 1);
+      int x1 = min(x0 + 1, D.n0 - 1);
+      const int y1 = min(y0 + 1, D.n1 - 1);
+      if (D.flip) { x0 = D.n0 - 1 - x0; x1 = D.n0 - 1 - x1; }
+      const int zb = min(z0, D.n2 - 2);
+      hi0[q] = z0 != zb;
+      const unsigned o00 = (unsigned)x0 * sx + (unsigned)y0 * sy + (unsigned)zb;
+      const unsigned o10 = (unsigned)x1 * sx + (unsigned)y0 * sy + (unsigned)zb;
+      const unsigned o01 = (unsigned)x0 * sx + (unsigned)y1 * sy + (unsigned)zb;
+      const unsigned o11 = (unsigned)x1 * sx + (unsigned)y1 * sy + (unsigned)zb;
+#ifdef FSG_WARP_SKIP_OUTSIDE
+      p00[q] = p10[q] = p01[q] = p11[q] = float2_u{0.f, 0.f};
+      if (ok[q])  // voxels that sample outside the volume (clamped onto a 0-face) need no data
+#endif
+      {
+        p00[q] = *reinterpret_cast<const float2_u*>(src_lin + o00);
+        p10[q] = *reinterpret_cast<const float2_u*>(src_lin + o10);
+        p01[q] = *reinterpret_cast<const float2_u*>(src_lin + o01);
+        p11[q] = *reinterpret_cast<const float2_u*>(src_lin + o11);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int k = kbase + 64 * (Q0 + q);
+    const bool live = k < D.n2;
+    if (HAS_NN && live) out_nn[row + k] = nn[q];
+    if (HAS_LIN) {
+      const float ax = 1.f - bx[q], ay = 1.f - by[q], az = 1.f - bz[q];
+      const float c000 = hi0[q] ? p00[q].y : p00[q].x, c001 = p00[q].y;
+      const float c100 = hi0[q] ? p10[q].y : p10[q].x, c101 = p10[q].y;
+      const float c010 = hi0[q] ? p01[q].y : p01[q].x, c011 = p01[q].y;
+      const float c110 = hi0[q] ? p11[q].y : p11[q].x, c111 = p11[q].y;
+      const float c00 = c000 * ax + c100 * bx[q];
+      const float c01 = c001 * ax + c101 * bx[q];
+      const float c10 = c010 * ax + c110 * bx[q];
+      const float c11 = c011 * ax + c111 * bx[q];
+      const float c0 = c00 * ay + c10 * by[q];
+      const float c1 = c01 * ay + c11 * by[q];
+      float v = ok[q] ? (c0 * az + c1 * bz[q]) : 0.f;
+      if (E.gamma > 0.f) {
+        // 300*(v/300)^g.  FAST: 300 * 2^(g*(log2 v - log2 300)) on v_log_f32 / v_exp_f32; else OCML powf and
+        // an IEEE division like ATen.  (|FAST - precise| < 1e-4 on the 0..255 scale, tests/test_hip_parity.py)
+        if (FAST) v = 300.0f * __builtin_amdgcn_exp2f(E.gamma * (__builtin_amdgcn_logf(v) - 8.2288186904958804f));
+        else v = 300.0f * powf(v / 300.0f, E.gamma);
+      }
+      if (E.bias) {
+        const fsg_tap cb = cbk[Q0 + q];
+        const float bval = fsg_mix(cb.w_lo, sm[nf + cb.lo], cb.w_hi, sm[nf + cb.hi]);
+        v = v * (FAST ? __builtin_amdgcn_exp2f(bval * 1.4426950408889634f) : expf(bval));
+      }
+      if (live) out_lin[row + k] = v;
+    }
+  }
+}
+
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
+__device__ __forceinline__ void warp_emit4(const FsgDeformK& D, const EpiK& E, const Margins& m, const float* sm,
+                                           int nf, int i, int j, int kbase, const fsg_tap (&ck)[4],
+                                           const fsg_tap (&cbk)[4], size_t row, const float* __restrict__ src_lin,
+                                           float* __restrict__ out_lin, const LT* __restrict__ src_nn,
+                                           LT* __restrict__ out_nn) {
+#define FSG_EMIT(Q0, NQ) \
+  warp_emitN<LT, HAS_LIN, HAS_NN, FAST, Q0, NQ>(D, E, m, sm, nf, i, j, kbase, ck, cbk, row, src_lin, out_lin, src_nn, out_nn)
+#if FSG_WARP_BATCH == 4
+  FSG_EMIT(0, 4);
+#elif FSG_WARP_BATCH == 2
+  FSG_EMIT(0, 2);
+  FSG_EMIT(2, 2);
+#else
+  FSG_EMIT(0, 1);
+  FSG_EMIT(1, 1);
+  FSG_EMIT(2, 1);
+  FSG_EMIT(3, 1);
+#endif
+#undef FSG_EMIT
+}
+
+// stage one row's coarse values into the wave's LDS slot
+__device__ __forceinline__ void stage_row(const FsgDeformK& D, const EpiK& E, int i, int j, int nf, int need,
+                                          const fsg_tap& ax, const fsg_tap& abx, float* sm, int lane) {
+  if (D.rows) {
+    const float* r = D.rows + ((size_t)i * D.n1 + j) * D.row_stride;
+    for (int e = lane; e < need; e += FSG_WAVE) sm[e] = r[e];
+  } else {
+    if (D.field) fill_row_xy<3>(D.field, D.f1, D.f2, ax, uniform_tap(D.ty, j), sm, lane);
+    if (E.bias) fill_row_xy<1>(E.bias, E.b1, E.b2, abx, uniform_tap(E.by, j), sm + nf, lane);
+  }
+}
+
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
+__global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+                                                        const float* __restrict__ src_lin,
+                                                        float* __restrict__ out_lin, const LT* __restrict__ src_nn,
+                                                        LT* __restrict__ out_nn, EpiK E) {
+  __shared__ float sm_all[4][2][ROWCAP];  // per wave, double buffered
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int i = tile / tiles_j;
+  const int jbase = (tile - i * tiles_j) * (4 * WARP_ROWS_PER_WAVE) + wave * WARP_ROWS_PER_WAVE;
+  const Margins m = load_margins(mm6);
+  const int nf = D.field ? 3 * D.f2 : 0;
+  const int need = nf + (E.bias ? E.b2 : 0);
+  const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
+  const bool onfly = D.rows == nullptr;
+  const fsg_tap ax = (onfly && D.field) ? uniform_tap(D.tx, i) : none;
+  const fsg_tap abx = (onfly && E.bias) ? uniform_tap(E.bx, i) : none;
+  // the z tables are the same for every row: keep this lane's entries in registers (n2 <= 256)
+  const bool cached = D.n2 <= 256;
+  fsg_tap ck[4], cbk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = min(lane + 64 * q, D.n2 - 1);
+    ck[q] = D.field ? D.tz[k] : none;
+    cbk[q] = E.bias ? E.bz[k] : none;
+  }
+  if (jbase < D.n1 && need) stage_row(D, E, i, jbase, nf, need, ax, abx, sm_all[wave][0], lane);
+  for (int r = 0; r < WARP_ROWS_PER_WAVE; ++r) {
+    const int j = jbase + r;
+    if (j >= D.n1) break;
+    const float* sm = sm_all[wave][r & 1];
+    wave_lds_sync();
+    // prefetch the next row's coarse values into the other buffer while this row's gathers are in flight
+    if (r + 1 < WARP_ROWS_PER_WAVE && j + 1 < D.n1 && need)
+      stage_row(D, E, i, j + 1, nf, need, ax, abx, sm_all[wave][(r + 1) & 1], lane);
+    const size_t row = ((size_t)i * D.n1 + j) * D.n2;
+    if (cached) {
+      warp_emit4<LT, HAS_LIN, HAS_NN, FAST>(D, E, m, sm, nf, i, j, lane, ck, cbk, row, src_lin, out_lin, src_nn,
+                                            out_nn);
+    } else {
+      for (int kb = 0; kb < D.n2; kb += 256) {
+        fsg_tap c4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = min(kb + lane + 64 * q, D.n2 - 1);
+          c4[q] = D.field ? D.tz[k] : none;
+          b4[q] = E.bias ? E.bz[k] : none;
+        }
+        warp_emit4<LT, HAS_LIN, HAS_NN, FAST>(D, E, m, sm, nf, i, j, kb + lane, c4, b4, row, src_lin, out_lin,
+                                              src_nn, out_nn);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, int32_t* __restrict__ mm6,
+                                                                 int rows_per_block) {
+  __shared__ float sm_all[4][ROWCAP];
+  __shared__ float red[6][4];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* sm = sm_all[wave];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const int rows = D.n0 * D.n1;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(rows, r_begin + rows_per_block);
+  const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
+  const bool cached = D.n2 <= 256;
+  fsg_tap ck[4];
+  if (cached) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane + 64 * q;
+      ck[q] = (D.field && k < D.n2) ? D.tz[k] : none;
+    }
+  }
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    const int i = r / D.n1, j = r - i * D.n1;
+    if (D.rows) {
+      const float* rr = D.rows + (size_t)r * D.row_stride;
+      for (int e = lane; e < 3 * D.f2; e += FSG_WAVE) sm[e] = rr[e];
+    } else if (D.field) {
+      fill_row_xy<3>(D.field, D.f1, D.f2, uniform_tap(D.tx, i), uniform_tap(D.ty, j), sm, lane);
+    }
+    wave_lds_sync();
+    if (cached) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < D.n2) {
+          float x, y, z;
+          row_position(D, sm, i, j, k, ck[q], x, y, z);
+          lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+          lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+          lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+        }
+      }
+    } else {
+      for (int k = lane; k < D.n2; k += FSG_WAVE) {
+        float x, y, z;
+        row_position(D, sm, i, j, k, D.field ? D.tz[k] : none, x, y, z);
+        lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+        lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+        lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+      }
+    }
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float l = fsg_wave_min(lo[a]), h = fsg_wave_max(hi[a]);
+    if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[a][0];
+    for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[a][w]) : fmaxf(v, red[a][w]);
+    if (a < 3) fsg_atomic_min_key(&mm6[a], v);
+    else fsg_atomic_max_key(&mm6[a], v);
+  }
+}
+
 // ---- fused warp -------------------------------------------------------------------------------
 template <typename LT>
 __global__ __launch_bounds__(256) void warp_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
@@ -171,6 +594,21 @@ int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, f
   EpiK E;
   rc = fill_epilogue(epi, E);
   if (rc) return rc;
+  const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
+  if (D.rows && D.row_stride < need) return FSG_E_BADARG;
+  if (need <= ROWCAP && D.n2 >= 2 && !(g_tuning_flags & FSG_TUNE_GENERIC_WARP)) {
+    const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
+    const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
+    const dim3 grid((unsigned)(D.n0 * tiles_j)), block(256);
+    hipStream_t st = fsg_stream(stream);
+#define FSG_LAUNCH_WARP(L, N, F) \
+  hipLaunchKernelGGL((warp_rows_kernel<LT, L, N, F>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+    if (src_lin && src_nn) { if (fast) FSG_LAUNCH_WARP(true, true, true); else FSG_LAUNCH_WARP(true, true, false); }
+    else if (src_lin)      { if (fast) FSG_LAUNCH_WARP(true, false, true); else FSG_LAUNCH_WARP(true, false, false); }
+    else                   { FSG_LAUNCH_WARP(false, true, true); }
+#undef FSG_LAUNCH_WARP
+    FSG_RETURN_LAUNCH();
+  }
   hipLaunchKernelGGL(warp_kernel<LT>, fsg_grid3(D.n0, D.n1, D.n2), fsg_block3(), 0, fsg_stream(stream), D, mm6,
                      src_lin, out_lin, src_nn, out_nn, E);
   FSG_RETURN_LAUNCH();
@@ -205,9 +643,32 @@ __global__ void mm_init_kernel(int32_t* mm, int nmin, int nmax) {
 
 extern "C" {
 
+int fsg_set_tuning(int flags) {
+  const int prev = g_tuning_flags;
+  g_tuning_flags = flags;
+  return prev;
+}
+
 int fsg_minmax_init(int32_t* mm, int nmin, int nmax, void* stream) {
   if (!mm || nmin < 0 || nmax < 0 || nmin + nmax <= 0 || nmin + nmax > 64) return FSG_E_BADARG;
   hipLaunchKernelGGL(mm_init_kernel, dim3(1), dim3(64), 0, fsg_stream(stream), mm, nmin, nmax);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_deform_rows_f32(const fsg_deform* d, const fsg_epilogue* epi, float* rows, int row_stride, void* stream) {
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  EpiK E;
+  rc = fill_epilogue(epi, E);
+  if (rc) return rc;
+  const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
+  if (!rows || row_stride < need) return FSG_E_BADARG;
+  if (need == 0) return 0;
+  size_t blocks = ((size_t)D.n0 * D.n1 * need + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(deform_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), D, E, rows,
+                     row_stride);
   FSG_RETURN_LAUNCH();
 }
 
@@ -217,6 +678,13 @@ int fsg_coords_minmax_f32(const fsg_deform* d, int32_t* mm6, void* stream) {
   if (rc) return rc;
   if (!mm6) return FSG_E_BADARG;
   const int rows = D.n0 * D.n1;
+  if ((D.field ? 3 * D.f2 : 0) <= ROWCAP && !(g_tuning_flags & FSG_TUNE_GENERIC_WARP)) {
+    int grid = (rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048;
+    const int rpb = (rows + grid - 1) / grid;
+    grid = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(coords_minmax_rows_kernel, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm6, rpb);
+    FSG_RETURN_LAUNCH();
+  }
   const int grid = rows < 2048 ? rows : 2048;
   hipLaunchKernelGGL(coords_minmax_kernel, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm6);
   FSG_RETURN_LAUNCH();

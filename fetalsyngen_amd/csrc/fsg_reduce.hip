@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-    atomicMin(&mm[0], fsg_f2key(lo));
-    atomicMax(&mm[1], fsg_f2key(hi));
+    fsg_atomic_min_key(&mm[0], lo);
+    fsg_atomic_max_key(&mm[1], hi);
   }
 }
 

@@ -94,8 +94,124 @@ __global__ __launch_bounds__(256) void zoom1_kernel(ZoomK Z, EpiZ E) {
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-      atomicMin(&E.mm_out[0], fsg_f2key(lo));
-      atomicMax(&E.mm_out[1], fsg_f2key(hi));
+      fsg_atomic_min_key(&E.mm_out[0], lo);
+      fsg_atomic_max_key(&E.mm_out[1], hi);
+    }
+  }
+}
+
+// ---- row-wise variant (tuned path) ------------------------------------------------------------------
+// One wave per output row (i, j, :): the x- and y-interpolation of the four source rows it depends on
+// is done once, coalesced, into a wave-private LDS row of sz floats; each output voxel is then one lerp
+// of two LDS values.  Global traffic per output row: 4 coalesced source rows (L1/L2 hits for the
+// neighbouring output rows that share them) + one coalesced store.  Same fp32 operation order as
+// fsg_tab_interp<1>, so results are bit-identical to the per-voxel kernel.
+constexpr int ZROWCAP = 1024;  // max source z extent handled by the row kernel
+
+__device__ __forceinline__ void zwave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ fsg_tap zuniform_tap(const fsg_tap* t, int idx) {
+  const int4 v = *reinterpret_cast<const int4*>(t + idx);
+  fsg_tap r;
+  r.lo = __builtin_amdgcn_readfirstlane(v.x);
+  r.hi = __builtin_amdgcn_readfirstlane(v.y);
+  r.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.z));
+  r.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.w));
+  return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void zoom_emit(const ZoomK& Z, const EpiZ& E, const float* sm, bool okr, const fsg_tap& c,
+                                          size_t o, float mx, float mnq, float den, float& lo, float& hi) {
+  float v = 0.f;
+  if (okr && c.lo >= 0) v = fsg_mix(c.w_lo, sm[c.lo], c.w_hi, sm[c.hi]);
+  if (EPI == EPI_STORE) {
+    Z.dst[o] = v;
+  } else if (EPI == EPI_NOISE_PTR) {
+    v = v + E.noise_std * E.noise[o];
+    Z.dst[o] = v < 0.f ? 0.f : v;
+  } else if (EPI == EPI_NOISE_PHILOX) {
+    v = v + E.noise_std * fsg_randn1(E.seed, E.stream_id, (uint64_t)o);
+    Z.dst[o] = v < 0.f ? 0.f : v;
+  } else if (EPI == EPI_MINMAX) {
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  } else {
+    float t = v / mx;
+    if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (t - mnq) / den;
+    Z.dst[o] = t;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void zoom1_rows_kernel(ZoomK Z, EpiZ E, int rows_per_block) {
+  __shared__ float sm_all[4][ZROWCAP];
+  __shared__ float red[2][4];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* sm = sm_all[wave];
+  float lo = INFINITY, hi = -INFINITY;
+  float mnq = 0.f, den = 1.f, mx = 1.f;
+  if (EPI == EPI_NORM) {
+    mx = fsg_key2f(E.mm_in[1]);
+    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    den = 1.0f - mnq;
+  }
+  const int nb = gridDim.x;
+  const int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int rows = Z.dx * Z.dy;
+  const int r_begin = tile * rows_per_block;
+  const int r_end = min(rows, r_begin + rows_per_block);
+  const bool cached = Z.dz <= 256;
+  fsg_tap ck[4];
+  if (cached) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane + 64 * q;
+      ck[q] = k < Z.dz ? Z.tz[k] : fsg_tap{-1, 0, 0.f, 0.f};
+    }
+  }
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    const int i = r / Z.dy, j = r - i * Z.dy;
+    const fsg_tap a = zuniform_tap(Z.tx, i), b = zuniform_tap(Z.ty, j);
+    const bool okr = a.lo >= 0 && b.lo >= 0;
+    if (okr) {
+      const float* p00 = Z.src + ((size_t)a.lo * Z.sy + b.lo) * Z.sz;
+      const float* p10 = Z.src + ((size_t)a.hi * Z.sy + b.lo) * Z.sz;
+      const float* p01 = Z.src + ((size_t)a.lo * Z.sy + b.hi) * Z.sz;
+      const float* p11 = Z.src + ((size_t)a.hi * Z.sy + b.hi) * Z.sz;
+      for (int zs = lane; zs < Z.sz; zs += FSG_WAVE) {
+        const float t0 = fsg_mix(a.w_lo, p00[zs], a.w_hi, p10[zs]);
+        const float t1 = fsg_mix(a.w_lo, p01[zs], a.w_hi, p11[zs]);
+        sm[zs] = fsg_mix(b.w_lo, t0, b.w_hi, t1);
+      }
+    }
+    zwave_sync();
+    const size_t row = (size_t)r * Z.dz;
+    if (cached) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < Z.dz) zoom_emit<EPI>(Z, E, sm, okr, ck[q], row + k, mx, mnq, den, lo, hi);
+      }
+    } else {
+      for (int k = lane; k < Z.dz; k += FSG_WAVE)
+        zoom_emit<EPI>(Z, E, sm, okr, Z.tz[k], row + k, mx, mnq, den, lo, hi);
+    }
+    zwave_sync();
+  }
+  if (EPI == EPI_MINMAX) {
+    lo = fsg_wave_min(lo);
+    hi = fsg_wave_max(hi);
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+      fsg_atomic_min_key(&E.mm_out[0], lo);
+      fsg_atomic_max_key(&E.mm_out[1], hi);
     }
   }
 }
@@ -111,6 +227,16 @@ int check(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg
 template <int EPI>
 int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   const int rows = Z.dx * Z.dy;
+  if (Z.sz <= ZROWCAP && !(g_tuning_flags & FSG_TUNE_GENERIC_ZOOM)) {
+    // 2048 blocks when there is enough work: >= 8 rows per block keeps neighbouring rows (shared source
+    // rows) on one CU, and the MINMAX variant issues only 2 atomics per block
+    int nblk = (rows + 7) / 8;
+    if (nblk > 2048) nblk = 2048;
+    if (nblk >= 8) nblk &= ~7;  // multiple of 8 for the XCD-contiguous tile order
+    const int rpb = (rows + nblk - 1) / nblk;
+    hipLaunchKernelGGL(zoom1_rows_kernel<EPI>, dim3(nblk), dim3(256), 0, fsg_stream(stream), Z, E, rpb);
+    FSG_RETURN_LAUNCH();
+  }
   const int grid = rows < 4096 ? rows : 4096;
   hipLaunchKernelGGL(zoom1_kernel<EPI>, dim3(grid), dim3(256), 0, fsg_stream(stream), Z, E);
   FSG_RETURN_LAUNCH();

@@ -143,6 +143,7 @@ class SpatialDeformation:
             return image, segmentation, output
         if spec is None:
             spec = self.make_spec(plan, output.shape, flip_in_kernel=True).build()
+        spec.prepare_rows(bias, bias_tabs)
         if mm6 is None:
             mm6 = K.coords_minmax(spec)
         seg = segmentation.to(self.device).contiguous()

@@ -70,6 +70,29 @@ class FetalSynthGen:
         self.device = device
         self.rng = rng  # None: module default (fetalsyngen_amd.rng.get_mode())
 
+    def prewarm(self, shape=None) -> int:
+        """Build and upload every per-axis table this configuration can ask for (the low-res size of
+        RandResample takes at most shape*(1 - min/max resolution) distinct values per axis; the coarse
+        deformation / bias grids a handful).  Optional: tables are otherwise cached on first use.
+        Returns the number of tables now resident."""
+        shape = tuple(int(v) for v in (shape or self.shape))
+        res = np.array(self.resolution, dtype=np.float64)
+        rs, sd, bf = self.resampled, self.spatial_deform, self.biasfield
+        n = 0
+        for a in range(3):
+            size = shape[a]
+            lo = int(size * res[a] / max(rs.max_resolution, res[a]))
+            for m in range(max(lo - 1, 1), size + 1):
+                K._device_table(T._resample_axis_table(m, size), self.device)
+                f = np.float64(m) / np.float64(size)
+                K._device_table(T.zoom_table(m, float(1 / f), int(np.round(m * (1 / f)))), self.device)
+                n += 2
+            for lo_s, hi_s in ((sd.nonlin_scale_min, sd.nonlin_scale_max), (bf.scale_min, bf.scale_max)):
+                for s_ in range(max(int(np.floor(lo_s * size)) - 1, 1), int(np.ceil(hi_s * size)) + 2):
+                    K._device_table(T.zoom_table(s_, float(np.float64(size) / np.float64(s_)), size), self.device)
+                    n += 1
+        return n
+
     def _validated_genparams(self, d):
         if not isinstance(d, dict):
             return d

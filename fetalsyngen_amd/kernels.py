@@ -16,8 +16,20 @@ from .tables import Arena, TAP_DTYPE
 F32 = torch.float32
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(ref=None):
+    """Raw hipStream_t of torch's current stream on `ref`'s device (tensor, device or None).
+
+    `torch.cuda.current_stream()` walks through availability checks (environment lookups) on every
+    call; the raw getter is ~100x cheaper and this sits in front of every launch."""
+    if isinstance(ref, torch.Tensor):
+        idx = ref.device.index
+    elif ref is None:
+        idx = torch.cuda.current_device()
+    else:
+        idx = torch.device(ref).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 def _need_gpu(*tensors):
@@ -48,29 +60,45 @@ def _dims3(t):
     return int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
 
 
+_DEV_TABLES: dict = {}  # (device, id(host table)) -> (device bytes, host table kept alive)
+_DEV_TABLES_MAX = 2048
+
+
+def _device_table(tab, device):
+    key = (str(device), id(tab))
+    hit = _DEV_TABLES.get(key)
+    if hit is not None and hit[1] is tab:
+        return hit[0]
+    if tab.dtype != TAP_DTYPE:
+        raise TypeError("tap table dtype")
+    raw = np.ascontiguousarray(tab).view(np.uint8).reshape(-1)
+    host = torch.empty(raw.size, dtype=torch.uint8, pin_memory=True)  # pinned: the copy below is async
+    host.numpy()[:] = raw
+    d = host.to(device, non_blocking=True)
+    if len(_DEV_TABLES) >= _DEV_TABLES_MAX:
+        _DEV_TABLES.pop(next(iter(_DEV_TABLES)))
+    _DEV_TABLES[key] = (d, tab)
+    return d
+
+
 class DeviceTables:
-    """Three per-axis tap tables resident on the device (one upload)."""
+    """Three per-axis tap tables resident on the device.
+
+    Tables produced by the cached builders in `tables.py` are uploaded once per device and reused
+    (the host array object is the cache key); ad-hoc tables are uploaded on first use."""
 
     def __init__(self, tabs, device, arena: Arena | None = None):
-        own = arena is None
-        arena = arena or Arena()
         self.lengths = tuple(len(t) for t in tabs)
-        for t in tabs:
-            if t.dtype != TAP_DTYPE:
-                raise TypeError("tap table dtype")
-        self._offs = [arena.add(t) for t in tabs]
-        self._arena = arena
-        if own:
-            arena.upload(device)
+        self._dev = [_device_table(t, device) for t in tabs]
 
     @property
     def ptrs(self):
-        return tuple(C.c_void_p(self._arena.ptr(o)) for o in self._offs)
+        return tuple(C.c_void_p(d.data_ptr()) for d in self._dev)
 
 
 def new_minmax(device, nmin=1, nmax=1):
     mm = torch.empty(nmin + nmax, dtype=torch.int32, device=device)
-    _lib.check(_lib.load().fsg_minmax_init(_p(mm), nmin, nmax, _stream()), "fsg_minmax_init")
+    _lib.check(_lib.load().fsg_minmax_init(_p(mm), nmin, nmax, _stream(mm)), "fsg_minmax_init")
     return mm
 
 
@@ -82,7 +110,7 @@ def key_to_float(key: int) -> float:
 def randn(shape, seed: int, stream_id: int, device) -> torch.Tensor:
     out = torch.empty(tuple(shape), dtype=F32, device=device)
     _need_gpu(out)
-    _lib.check(_lib.load().fsg_randn_f32(_p(out), out.numel(), seed, stream_id, _stream()), "fsg_randn_f32")
+    _lib.check(_lib.load().fsg_randn_f32(_p(out), out.numel(), seed, stream_id, _stream(out)), "fsg_randn_f32")
     return out
 
 
@@ -103,7 +131,7 @@ def gmm_sample(labels, mus, sigmas, noise=None, seed=0, stream_id=0) -> torch.Te
     else:
         raise TypeError("labels must be uint8 or int64")
     _lib.check(fn(_p(labels), labels.numel(), _p(mus), _p(sigmas), ntab, _p(noise), seed, stream_id, _p(out),
-                  _stream()), name)
+                  _stream(out)), name)
     return out
 
 
@@ -117,7 +145,7 @@ def label_stats(labels_u8, values, nlabels: int):
     s1 = torch.zeros(nlabels, dtype=torch.float64, device=dev)
     s2 = torch.zeros(nlabels, dtype=torch.float64, device=dev)
     _lib.check(_lib.load().fsg_label_stats_u8(_p(labels_u8), _p(values), values.numel(), nlabels, _p(cnt), _p(s1),
-                                              _p(s2), _stream()), "fsg_label_stats_u8")
+                                              _p(s2), _stream(values)), "fsg_label_stats_u8")
     n = cnt.clamp(min=1).double()
     mean = s1 / n
     return cnt, mean, s2 / n - mean * mean
@@ -145,7 +173,7 @@ def zoom3d(src, tabs: DeviceTables) -> torch.Tensor:
     shape = (dx, dy, dz) if nch == 1 else (dx, dy, dz, nch)
     dst = torch.empty(shape, dtype=F32, device=src.device)
     tx, ty, tz = tabs.ptrs
-    _lib.check(_lib.load().fsg_zoom3d_f32(_p(src), sx, sy, sz, nch, tx, ty, tz, _p(dst), dx, dy, dz, _stream()),
+    _lib.check(_lib.load().fsg_zoom3d_f32(_p(src), sx, sy, sz, nch, tx, ty, tz, _p(dst), dx, dy, dz, _stream(src)),
                "fsg_zoom3d_f32")
     return dst
 
@@ -164,7 +192,7 @@ def resample_noise(src, tabs: DeviceTables, noise_std=0.0, noise=None, seed=None
         mode = 2
     tx, ty, tz = tabs.ptrs
     _lib.check(_lib.load().fsg_resample_noise_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz, mode,
-                                                  _p(noise), seed or 0, stream_id, float(noise_std), _stream()),
+                                                  _p(noise), seed or 0, stream_id, float(noise_std), _stream(src)),
                "fsg_resample_noise_f32")
     return dst
 
@@ -174,7 +202,7 @@ def zoom_minmax(src, tabs: DeviceTables) -> torch.Tensor:
     dx, dy, dz = tabs.lengths
     mm = new_minmax(src.device)
     tx, ty, tz = tabs.ptrs
-    _lib.check(_lib.load().fsg_zoom3d_minmax_f32(_p(src), sx, sy, sz, tx, ty, tz, dx, dy, dz, _p(mm), _stream()),
+    _lib.check(_lib.load().fsg_zoom3d_minmax_f32(_p(src), sx, sy, sz, tx, ty, tz, dx, dy, dz, _p(mm), _stream(src)),
                "fsg_zoom3d_minmax_f32")
     return mm
 
@@ -186,7 +214,7 @@ def zoom_normalise(src, tabs: DeviceTables, mm, mode: int) -> torch.Tensor:
     dst = torch.empty((dx, dy, dz), dtype=F32, device=src.device)
     tx, ty, tz = tabs.ptrs
     _lib.check(_lib.load().fsg_zoom3d_normalise_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz, _p(mm),
-                                                    mode, _stream()), "fsg_zoom3d_normalise_f32")
+                                                    mode, _stream(src)), "fsg_zoom3d_normalise_f32")
     return dst
 
 
@@ -218,18 +246,52 @@ class DeformSpec:
             self._keep += [field_small, field_tabs]
         else:
             d.field_dims[:] = [0, 0, 0]
+        d.rows, d.row_stride = None, 0
         self.c = d
+
+    def prepare_rows(self, bias=None, bias_tabs=None):
+        """Precompute the per-(x,y) coarse rows (displacement, and bias when it will be fused into the
+        warp) into a workspace; later min/max and warp launches start each row with one coalesced load."""
+        f2 = int(self.c.field_dims[2])
+        b2 = int(bias.shape[2]) if bias is not None else 0
+        need = 3 * f2 + b2
+        if need == 0 or need > 512:
+            return self
+        stride = (need + 3) // 4 * 4
+        rows = torch.empty(self.shape[0] * self.shape[1] * stride, dtype=F32, device=self.device)
+        epi = _epilogue(None, bias, bias_tabs, self.shape)
+        _lib.check(_lib.load().fsg_deform_rows_f32(C.byref(self.c), C.byref(epi), _p(rows), stride, _stream(rows)),
+                   "fsg_deform_rows_f32")
+        self.c.rows, self.c.row_stride = rows.data_ptr(), stride
+        self._keep.append(rows)
+        self._rows_bias = b2
+        return self
+
+
+def _epilogue(gamma, bias, bias_tabs, shape):
+    epi = _lib.Epilogue()
+    epi.gamma = float(np.float32(gamma)) if gamma is not None else 0.0
+    if bias is not None:
+        _need_gpu(bias)
+        _f32(bias)
+        if bias_tabs.lengths != tuple(shape):
+            raise ValueError("bias tables must have the grid's lengths")
+        epi.bias_dims[:] = _dims3(bias)
+        epi.bias = bias.data_ptr()
+        bx, by, bz = bias_tabs.ptrs
+        epi.bx, epi.by, epi.bz = bx.value, by.value, bz.value
+    return epi
 
 
 def coords_minmax(spec: DeformSpec) -> torch.Tensor:
     mm6 = new_minmax(spec.device, 3, 3)
-    _lib.check(_lib.load().fsg_coords_minmax_f32(C.byref(spec.c), _p(mm6), _stream()), "fsg_coords_minmax_f32")
+    _lib.check(_lib.load().fsg_coords_minmax_f32(C.byref(spec.c), _p(mm6), _stream(mm6)), "fsg_coords_minmax_f32")
     return mm6
 
 
 def coords(spec: DeformSpec, mm6):
     out = [torch.empty(spec.shape, dtype=F32, device=spec.device) for _ in range(3)]
-    _lib.check(_lib.load().fsg_coords_f32(C.byref(spec.c), _p(mm6), _p(out[0]), _p(out[1]), _p(out[2]), _stream()),
+    _lib.check(_lib.load().fsg_coords_f32(C.byref(spec.c), _p(mm6), _p(out[0]), _p(out[1]), _p(out[2]), _stream(mm6)),
                "fsg_coords_f32")
     return out
 
@@ -242,16 +304,9 @@ def warp(spec: DeformSpec, mm6, src_lin=None, src_nn=None, gamma=None, bias=None
             raise ValueError(f"volume shape {tuple(s.shape)} != grid {spec.shape}")
     out_lin = torch.empty_like(_f32(src_lin)) if src_lin is not None else None
     out_nn = torch.empty_like(src_nn) if src_nn is not None else None
-    epi = _lib.Epilogue()
-    epi.gamma = float(np.float32(gamma)) if gamma is not None else 0.0
-    if bias is not None:
-        _f32(bias)
-        if bias_tabs.lengths != spec.shape:
-            raise ValueError("bias tables must have the grid's lengths")
-        epi.bias_dims[:] = _dims3(bias)
-        epi.bias = bias.data_ptr()
-        bx, by, bz = bias_tabs.ptrs
-        epi.bx, epi.by, epi.bz = bx.value, by.value, bz.value
+    epi = _epilogue(gamma, bias, bias_tabs, spec.shape)
+    if spec.c.rows and (int(bias.shape[2]) if bias is not None else 0) > getattr(spec, "_rows_bias", 0):
+        raise ValueError("row workspace was prepared without this bias grid; call prepare_rows(bias, bias_tabs)")
     lib = _lib.load()
     if src_nn is None or src_nn.dtype == F32:
         fn, name = lib.fsg_warp_f32, "fsg_warp_f32"
@@ -259,7 +314,7 @@ def warp(spec: DeformSpec, mm6, src_lin=None, src_nn=None, gamma=None, bias=None
         fn, name = lib.fsg_warp_f32_u8, "fsg_warp_f32_u8"
     else:
         raise TypeError("nearest-neighbour volume must be float32 or uint8")
-    _lib.check(fn(C.byref(spec.c), _p(mm6), _p(src_lin), _p(out_lin), _p(src_nn), _p(out_nn), C.byref(epi), _stream()),
+    _lib.check(fn(C.byref(spec.c), _p(mm6), _p(src_lin), _p(out_lin), _p(src_nn), _p(out_nn), C.byref(epi), _stream(mm6)),
                name)
     return out_lin, out_nn
 
@@ -275,7 +330,7 @@ def interp3d(src, ii, jj, kk, mode: str, default_value=0.0) -> torch.Tensor:
         raise Exception("mode must be linear or nearest")
     dst = torch.empty(ii.shape, dtype=F32, device=src.device)
     _lib.check(_lib.load().fsg_interp3d_f32(_p(src), sx, sy, sz, _p(ii), _p(jj), _p(kk), ii.numel(),
-                                            1 if mode == "nearest" else 0, float(default_value), _p(dst), _stream()),
+                                            1 if mode == "nearest" else 0, float(default_value), _p(dst), _stream(src)),
                "fsg_interp3d_f32")
     return dst
 
@@ -284,7 +339,7 @@ def interp3d(src, ii, jj, kk, mode: str, default_value=0.0) -> torch.Tensor:
 def gamma(x, g: float) -> torch.Tensor:
     _need_gpu(x)
     out = torch.empty_like(_f32(x))
-    _lib.check(_lib.load().fsg_gamma_f32(_p(x), x.numel(), float(np.float32(g)), _p(out), _stream()), "fsg_gamma_f32")
+    _lib.check(_lib.load().fsg_gamma_f32(_p(x), x.numel(), float(np.float32(g)), _p(out), _stream(x)), "fsg_gamma_f32")
     return out
 
 
@@ -296,7 +351,7 @@ def bias_mul(x, bias, bias_tabs: DeviceTables) -> torch.Tensor:
         raise ValueError("bias tables must have the volume's lengths")
     out = torch.empty_like(x)
     bx, by, bz = bias_tabs.ptrs
-    _lib.check(_lib.load().fsg_bias_mul_f32(_p(x), nx, ny, nz, _p(bias), b0, b1, b2, bx, by, bz, _p(out), _stream()),
+    _lib.check(_lib.load().fsg_bias_mul_f32(_p(x), nx, ny, nz, _p(bias), b0, b1, b2, bx, by, bz, _p(out), _stream(x)),
                "fsg_bias_mul_f32")
     return out
 
@@ -307,7 +362,7 @@ def add_noise(x, noise_std: float, noise=None, seed=0, stream_id=0) -> torch.Ten
     if noise is not None and _f32(noise).numel() != x.numel():
         raise ValueError("noise size")
     _lib.check(_lib.load().fsg_add_noise_f32(_p(x), x.numel(), _p(noise), seed, stream_id, float(noise_std), _p(out),
-                                             _stream()), "fsg_add_noise_f32")
+                                             _stream(x)), "fsg_add_noise_f32")
     return out
 
 
@@ -322,10 +377,10 @@ def blur_axis(x, axis: int, taps: np.ndarray, force_generic=False) -> torch.Tens
     rc = _lib.E_ALIGN
     if not force_generic and len(taps) <= 129:
         rc = lib.fsg_blur_axis_taps_host_f32(_p(x), _p(out), nx, ny, nz, axis,
-                                             taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps), _stream())
+                                             taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps), _stream(x))
     if rc == _lib.E_ALIGN:  # shape not covered by the tuned kernels -> generic kernel (still HIP)
         tdev = torch.from_numpy(taps).to(x.device)
-        rc = lib.fsg_blur_axis_f32(_p(x), _p(out), nx, ny, nz, axis, _p(tdev), len(taps), _stream())
+        rc = lib.fsg_blur_axis_f32(_p(x), _p(out), nx, ny, nz, axis, _p(tdev), len(taps), _stream(x))
     _lib.check(rc, "fsg_blur_axis")
     return out
 
@@ -333,12 +388,12 @@ def blur_axis(x, axis: int, taps: np.ndarray, force_generic=False) -> torch.Tens
 def reduce_minmax(x) -> torch.Tensor:
     _need_gpu(x)
     mm = new_minmax(x.device)
-    _lib.check(_lib.load().fsg_reduce_minmax_f32(_p(_f32(x)), x.numel(), _p(mm), _stream()), "fsg_reduce_minmax_f32")
+    _lib.check(_lib.load().fsg_reduce_minmax_f32(_p(_f32(x)), x.numel(), _p(mm), _stream(x)), "fsg_reduce_minmax_f32")
     return mm
 
 
 def scale(x, mm, mode: int) -> torch.Tensor:
     _need_gpu(x, mm)
     out = torch.empty_like(_f32(x))
-    _lib.check(_lib.load().fsg_scale_f32(_p(x), x.numel(), _p(mm), mode, _p(out), _stream()), "fsg_scale_f32")
+    _lib.check(_lib.load().fsg_scale_f32(_p(x), x.numel(), _p(mm), mode, _p(out), _stream(x)), "fsg_scale_f32")
     return out

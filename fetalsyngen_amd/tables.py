@@ -11,6 +11,8 @@ weights the kernels consume are bit-identical to the reference's:
 """
 from __future__ import annotations
 
+from functools import lru_cache
+
 import numpy as np
 import torch
 
@@ -23,8 +25,11 @@ def _pack(lo, hi, w_lo, w_hi) -> np.ndarray:
     return t
 
 
+@lru_cache(maxsize=1024)
 def zoom_table(n_src: int, factor: float, n_dst: int) -> np.ndarray:
-    """One axis of the separable linear zoom: n_dst samples of an n_src-long axis."""
+    """One axis of the separable linear zoom: n_dst samples of an n_src-long axis.
+    Cached: the same (read-only) array object is returned for the same arguments, which also lets the
+    device-side copy be reused (kernels.DeviceTables)."""
     delta = (1.0 - factor) / (2.0 * factor)
     pos = torch.arange(delta, delta + n_dst / factor, 1 / factor, dtype=torch.float32)[:n_dst]
     pos = pos.clamp_(min=0).clamp_(max=n_src - 1)
@@ -32,7 +37,9 @@ def zoom_table(n_src: int, factor: float, n_dst: int) -> np.ndarray:
     hi = torch.clamp(lo + 1, max=n_src - 1)
     w_hi = pos - lo
     w_lo = 1 - w_hi
-    return _pack(lo.numpy(), hi.numpy(), w_lo.numpy(), w_hi.numpy())
+    tab = _pack(lo.numpy(), hi.numpy(), w_lo.numpy(), w_hi.numpy())
+    tab.setflags(write=False)
+    return tab
 
 
 def zoom_tables(src_shape, factor):
@@ -66,19 +73,37 @@ def resample_plan(in_shape, resolution, spacing, u_std: float):
     stds[spacing <= resolution] = 0.0
     new_size = (size * resolution / spacing).astype(int)
     factors = new_size / size
-    delta = (1.0 - factors) / (2.0 * factors)
-    tabs = []
-    for a in range(3):
-        pos = np.arange(delta[a], delta[a] + new_size[a] / factors[a], 1 / factors[a])[: new_size[a]]
-        tabs.append(position_table(pos, int(size[a])))
+    tabs = [_resample_axis_table(int(new_size[a]), int(size[a])) for a in range(3)]
     return stds, tuple(int(v) for v in new_size), factors, tabs
 
 
+@lru_cache(maxsize=1024)
+def _resample_axis_table(n_new: int, n_src: int) -> np.ndarray:
+    """Sample positions of RandResample along one axis depend only on (new size, size)."""
+    factor = np.float64(n_new) / np.float64(n_src)  # == (new_size / size)[a]
+    delta = (1.0 - factor) / (2.0 * factor)
+    pos = np.arange(delta, delta + n_new / factor, 1 / factor)[:n_new]
+    tab = position_table(pos, n_src)
+    tab.setflags(write=False)
+    return tab
+
+
+@lru_cache(maxsize=256)
 def gaussian_taps(sigma: float) -> np.ndarray:
     half = int(np.ceil(3 * sigma))
     t = torch.linspace(-half, half, 2 * half + 1, dtype=torch.float32)
     g = torch.exp(-((t / sigma) ** 2) / 2)
     return (g / g.sum()).numpy()
+
+
+_PIN = None
+
+
+def _can_pin() -> bool:
+    global _PIN
+    if _PIN is None:  # torch.cuda.is_available() is slow (environment lookups): ask once
+        _PIN = bool(torch.cuda.is_available())
+    return _PIN
 
 
 class Arena:
@@ -101,7 +126,7 @@ class Arena:
         return off
 
     def upload(self, device) -> torch.Tensor:
-        host = torch.empty(max(self._size, self.ALIGN), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        host = torch.empty(max(self._size, self.ALIGN), dtype=torch.uint8, pin_memory=_can_pin())
         hv = host.numpy()
         for off, arr in self._items:
             hv[off : off + arr.nbytes] = arr.view(np.uint8).reshape(-1)

@@ -45,6 +45,8 @@ typedef struct fsg_tap {
 
 /* Parameters of the spatial deformation (affine o nonlinear field), see fsg_coords_* / fsg_warp_*.
  * Passed BY POINTER from host memory; copied into the kernel arguments at launch. */
+struct fsg_epilogue;
+
 typedef struct fsg_deform {
   int32_t shape[3];      /* grid being generated == shape of the volumes being sampled            */
   float A[9];            /* row-major 3x3 affine, fp32 (affine_nonrigid.py:265-269)                */
@@ -56,10 +58,19 @@ typedef struct fsg_deform {
   const fsg_tap* tx;     /* DEVICE per-axis zoom tables coarse->shape, lengths shape[0..2]         */
   const fsg_tap* ty;
   const fsg_tap* tz;
+  const float* rows;     /* DEVICE, optional (NULL = off): per-(x,y) coarse rows from fsg_deform_rows_f32 */
+  int32_t row_stride;    /* floats per row in `rows`, >= 3*field_dims[2] (+ bias_dims[2] when fused)      */
 } fsg_deform;
 
 int fsg_abi_version(void);
 const char* fsg_error_string(int code);
+
+/* Process-wide tuning switches (tests use them to cross-check the tuned kernels against the plain
+ * ones); returns the previous flags.  Results are within the documented tolerances either way. */
+#define FSG_TUNE_GENERIC_WARP 1  /* per-voxel field evaluation instead of the row-wise LDS kernels */
+#define FSG_TUNE_PRECISE_MATH 2  /* OCML powf/expf in the gamma/bias epilogue instead of v_log/v_exp */
+#define FSG_TUNE_GENERIC_ZOOM 4  /* per-voxel 8-tap zoom instead of the row-wise LDS kernels */
+int fsg_set_tuning(int flags);
 
 /* ---- RNG ------------------------------------------------------------------------------------ */
 /* Standard-normal field from Philox4x32-10 keyed (seed, stream_id), element e uses counter e/4,
@@ -108,6 +119,12 @@ int fsg_zoom3d_normalise_f32(const float* src, int sx, int sy, int sz, const fsg
 /* ---- K2/K3: deformation coordinates (affine_nonrigid.py:64-84, :299-366) ----------------------- */
 /* Reset six int32 keys to (+inf,+inf,+inf,-inf,-inf,-inf) / two keys to (+inf,-inf). */
 int fsg_minmax_init(int32_t* mm, int npairs_min, int npairs_max, void* stream);
+/* Optional accelerator for fsg_coords_minmax_f32 / fsg_warp_*: x/y-interpolate the coarse displacement grid
+ * (and the coarse bias grid of `epi_host`, may be NULL) once per (x,y) column into `rows`
+ * (shape[0]*shape[1]*row_stride floats, caller-owned workspace); then set d->rows / d->row_stride.
+ * Results are bit-identical with or without it. */
+int fsg_deform_rows_f32(const fsg_deform* d_host, const struct fsg_epilogue* epi_host, float* rows, int row_stride,
+                        void* stream);
 /* min / max over the grid of the clamped coordinates, before margin subtraction; mm6 = {min x,y,z,
  * max x,y,z} as ordered int32 keys.  Reads only the coarse field. */
 int fsg_coords_minmax_f32(const fsg_deform* d_host, int32_t* mm6, void* stream);

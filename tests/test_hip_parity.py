@@ -409,3 +409,76 @@ def test_errors(K):
         K.gamma(torch.zeros(4, 4, 4), 1.0)
     with pytest.raises(RuntimeError, match="MI355X only"):
         make_generator((16, 16, 16), "cpu")
+
+
+# ---- tuned kernels vs plain kernels (fsg_set_tuning) --------------------------------------------------
+def test_rowwise_kernels_equal_per_voxel_kernels(K, golden):
+    """Row-wise LDS kernels (warp, coordinate min/max, zoom family) must reproduce the per-voxel kernels
+    bit for bit; the fast gamma/bias epilogue (v_log/v_exp) stays within the stage tolerance."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import tables as T
+
+    lib = _lib.load()
+    rs = np.random.RandomState(8)
+    shape = (72, 60, 100)
+    fs = (rs.randn(5, 4, 7, 3) * 2).astype(np.float32)
+    ht, new = T.zoom_tables(fs.shape[:3], np.array(shape) / np.array(fs.shape[:3]))
+    assert new == shape
+    A = np.array([[1.02, 0.05, -0.03], [-0.04, 0.97, 0.06], [0.02, -0.05, 1.04]], dtype=np.float32)
+    c = (np.array(shape) - 1) / 2
+    img = (rs.rand(*shape) * 255).astype(np.float32)
+    lab = rs.randint(0, 8, shape).astype(np.float32)
+    bias = (rs.randn(3, 2, 4) * 0.3).astype(np.float32)
+    bt, _ = T.zoom_tables(bias.shape, np.array(shape) / np.array(bias.shape))
+    res = {}
+    for flags in (0, 1, 2, 3):
+        prev = lib.fsg_set_tuning(flags)
+        try:
+            for flip in (False, True):
+                spec = K.DeformSpec(shape, A, c, c.astype(np.float32) + np.float32(0.4), flip, dev(fs),
+                                    K.DeviceTables(ht, DEV), device=DEV)
+                mm6 = K.coords_minmax(spec)
+                out, seg = K.warp(spec, mm6, src_lin=dev(img), src_nn=dev(lab), gamma=1.13, bias=dev(bias),
+                                  bias_tabs=K.DeviceTables(bt, DEV))
+                plain, _ = K.warp(spec, mm6, src_lin=dev(img))
+                res[(flags, flip)] = (host(mm6), host(out), host(seg), host(plain))
+                if flags in (0, 2):  # the same again through the precomputed row workspace
+                    spec.prepare_rows(dev(bias), K.DeviceTables(bt, DEV))
+                    mm6w = K.coords_minmax(spec)
+                    outw, segw = K.warp(spec, mm6w, src_lin=dev(img), src_nn=dev(lab), gamma=1.13, bias=dev(bias),
+                                        bias_tabs=K.DeviceTables(bt, DEV))
+                    plainw, _ = K.warp(spec, mm6w, src_lin=dev(img))
+                    _, seg8w = K.warp(spec, mm6w, src_nn=dev(lab.astype(np.uint8)))
+                    assert np.array_equal(host(mm6w), host(mm6)) and np.array_equal(host(outw), host(out))
+                    assert np.array_equal(host(segw), host(seg)) and np.array_equal(host(plainw), host(plain))
+                    assert np.array_equal(host(seg8w), host(seg).astype(np.uint8))
+        finally:
+            lib.fsg_set_tuning(prev)
+    for flip in (False, True):
+        base = res[(3, flip)]  # per-voxel kernels, OCML math
+        for flags in (0, 1, 2):
+            mm, out, seg, plain = res[(flags, flip)]
+            assert np.array_equal(mm, base[0]) and np.array_equal(seg, base[2]) and np.array_equal(plain, base[3])
+            if flags & 2 or flags == 1:
+                pass
+            np.testing.assert_allclose(out, base[1], rtol=RTOL, atol=ATOL)
+        assert np.array_equal(res[(2, flip)][1], base[1])  # rows + precise math == per-voxel + precise math
+    # zoom family
+    src = (rs.rand(37, 29, 41) * 255).astype(np.float32)
+    tabs, _ = T.zoom_tables(src.shape, np.array((64, 80, 96)) / np.array(src.shape))
+    outs = []
+    for flags in (0, 4):
+        prev = lib.fsg_set_tuning(flags)
+        try:
+            dt = K.DeviceTables(tabs, DEV)
+            z = K.zoom3d(dev(src), dt)
+            mm = K.zoom_minmax(dev(src), dt)
+            n0 = K.zoom_normalise(dev(src), dt, mm, 0)
+            n1 = K.zoom_normalise(dev(src), dt, mm, 1)
+            zn = K.resample_noise(dev(src), dt, noise_std=7.5, seed=42, stream_id=2)
+            outs.append([host(v) for v in (z, mm, n0, n1, zn)])
+        finally:
+            lib.fsg_set_tuning(prev)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][0], O.linear_zoom(t(src), np.array((64, 80, 96)) / np.array(src.shape)).numpy())

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmark at 256^3 (or --size): HIP-event timing of each kernel of the path in
+isolation, with the algorithmic bytes of DESIGN.md.  Also the target of `rocprofv3 --pmc` runs.
+
+    python tools/kernel_bench.py [--size 256] [--reps 20] [--only warp,blur] [--cold]
+"""
+import argparse, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+from fetalsyngen_amd import kernels as K, tables as T
+from fetalsyngen_amd.phantom import make_seed_volumes, combined_seed_labels
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=256)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--only", default="")
+ap.add_argument("--m", type=int, default=171, help="low-res size for the resample kernels")
+ap.add_argument("--rot", type=float, default=12.0, help="rotation (degrees) about each axis")
+args = ap.parse_args()
+dev = "cuda:0"
+n = args.size
+shape = (n, n, n)
+N = n ** 3
+only = set(args.only.split(",")) if args.only else None
+
+def timeit(name, fn, bytes_alg):
+    if only and not any(name.startswith(o) for o in only):
+        return
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.reps
+    print(json.dumps({"kernel": name, "us": round(us, 2), "alg_MB": round(bytes_alg / 1e6, 1),
+                      "GBps": round(bytes_alg / us / 1e3, 1)}), flush=True)
+
+rs = np.random.RandomState(0)
+seg, seeds = make_seed_volumes(shape)
+lab8 = torch.from_numpy(combined_seed_labels(seeds, {1: 3, 2: 4, 3: 2, 4: 5})).to(dev)
+segf = torch.from_numpy(seg).to(dev)
+seg8 = segf.to(torch.uint8)
+mus = torch.from_numpy((25 + 200 * rs.rand(50)).astype(np.float32)).to(dev)
+sig = torch.from_numpy((5 + 20 * rs.rand(50)).astype(np.float32)).to(dev)
+img = K.gmm_sample(lab8, mus, sig, seed=1, stream_id=1)
+
+timeit("gmm_u8_philox", lambda: K.gmm_sample(lab8, mus, sig, seed=1, stream_id=1), 5 * N)
+
+# deformation as the default config draws it
+from fetalsyngen_amd.utils.generation import make_affine_matrix
+r = np.deg2rad(args.rot)
+A = make_affine_matrix([r, -r, r], [0.01, -0.02, 0.015], [1.05, 0.95, 1.02]).astype(np.float32)
+fsz = max(1, round(0.05 * n))
+fs = torch.from_numpy((rs.randn(fsz, fsz, fsz, 3) * 2.5).astype(np.float32)).to(dev)
+ft, _ = T.zoom_tables((fsz,) * 3, np.array(shape) / fsz)
+c = (np.array(shape) - 1) / 2
+spec = K.DeformSpec(shape, A, c, c.astype(np.float32), True, fs, K.DeviceTables(ft, dev), device=dev)
+bsz = max(1, round(0.012 * n))
+bias = torch.from_numpy((rs.randn(bsz, bsz, bsz) * 0.2).astype(np.float32)).to(dev)
+bt, _ = T.zoom_tables((bsz,) * 3, np.array(shape) / bsz)
+btabs = K.DeviceTables(bt, dev)
+mm6 = K.coords_minmax(spec)
+timeit("coords_minmax", lambda: K.coords_minmax(spec), 0)
+timeit("warp_f32_f32_epi", lambda: K.warp(spec, mm6, src_lin=img, src_nn=segf, gamma=1.1, bias=bias, bias_tabs=btabs), 16 * N)
+timeit("warp_f32_u8_epi", lambda: K.warp(spec, mm6, src_lin=img, src_nn=seg8, gamma=1.1, bias=bias, bias_tabs=btabs), 10 * N)
+timeit("warp_lin_only", lambda: K.warp(spec, mm6, src_lin=img), 8 * N)
+timeit("warp_nn_f32_only", lambda: K.warp(spec, mm6, src_nn=segf), 8 * N)
+
+specw = K.DeformSpec(shape, A, c, c.astype(np.float32), True, fs, K.DeviceTables(ft, dev), device=dev)
+timeit("deform_rows_prepare", lambda: specw.prepare_rows(bias, btabs), 0)
+specw.prepare_rows(bias, btabs)
+timeit("coords_minmax_ws", lambda: K.coords_minmax(specw), 0)
+timeit("warp_f32_f32_epi_ws", lambda: K.warp(specw, mm6, src_lin=img, src_nn=segf, gamma=1.1, bias=bias, bias_tabs=btabs), 16 * N)
+timeit("warp_f32_u8_epi_ws", lambda: K.warp(specw, mm6, src_lin=img, src_nn=seg8, gamma=1.1, bias=bias, bias_tabs=btabs), 10 * N)
+timeit("warp_lin_only_ws", lambda: K.warp(specw, mm6, src_lin=img), 8 * N)
+timeit("warp_nn_f32_only_ws", lambda: K.warp(specw, mm6, src_nn=segf), 8 * N)
+
+for sigma in (0.6, 1.3, 1.77):
+    taps = T.gaussian_taps(sigma)
+    for axis in range(3):
+        timeit(f"blur_axis{axis}_R{len(taps)//2}", lambda: K.blur_axis(img, axis, taps), 8 * N)
+
+m = args.m
+stds, new, fac, rtabs = T.resample_plan(shape, [0.5] * 3, [0.5 * n / m] * 3, 0.5)
+rt = K.DeviceTables(rtabs, dev)
+M = int(np.prod(new))
+low = K.resample_noise(img, rt, noise_std=9.0, seed=3, stream_id=2)
+timeit(f"resample_noise_m{new[0]}", lambda: K.resample_noise(img, rt, noise_std=9.0, seed=3, stream_id=2), 4 * N + 4 * M)
+bt2, _ = T.zoom_tables(new, 1 / np.asarray(fac))
+zt = K.DeviceTables(bt2, dev)
+mm = K.zoom_minmax(low, zt)
+timeit(f"zoom_minmax_m{new[0]}", lambda: K.zoom_minmax(low, zt), 4 * M)
+timeit(f"zoom_normalise_m{new[0]}", lambda: K.zoom_normalise(low, zt, mm, 1), 4 * M + 4 * N)
+timeit("reduce_minmax", lambda: K.reduce_minmax(img), 4 * N)
+timeit("scale", lambda: K.scale(img, K.reduce_minmax(img), 1), 12 * N)
