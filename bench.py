@@ -47,6 +47,42 @@ def build_generator(shape, device, rng_mode):
         noise=RandNoise(p, 5, 15), gamma=RandGamma(p, 0.1), rng=rng_mode)
 
 
+def blur_traffic_per_launch(passes, size):
+    """HBM-side bytes per blur launch from the committed PMC summary (profiles/r*_blur_pmc.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate rocprofv3 --pmc passes of the same kernels, gfx950 x2 fetch
+    correction applied), averaged over the (axis, radius) mix this run actually launched."""
+    files = sorted((REPO / "profiles").glob("r*_blur_pmc.json"))
+    if not files or not passes:
+        return None
+    table = json.loads(files[-1].read_text())["sizes"].get(str(size))
+    if not table:
+        return None
+
+    def lookup(prefix, R):
+        pts = {}
+        for k, v in table.items():
+            if k.startswith(prefix):
+                pts[int(k[len(prefix):].split(",")[0].rstrip(">"))] = v["traffic_bytes"]
+        if not pts:
+            return None
+        rs = sorted(pts)
+        if R <= rs[0]:
+            return pts[rs[0]]
+        if R >= rs[-1]:
+            return pts[rs[-1]]
+        for lo_, hi_ in zip(rs, rs[1:]):
+            if lo_ <= R <= hi_:
+                return pts[lo_] + (pts[hi_] - pts[lo_]) * (R - lo_) / (hi_ - lo_)
+
+    tot, n = 0.0, 0
+    for axis, R in passes:
+        t = lookup("blur_contig_lds<" if axis == 2 else "blur_strided_v4<", R)
+        if t is None:
+            return None
+        tot, n = tot + t, n + 1
+    return round(tot / n)
+
+
 def blur_microbench(shape, device, sigma=1.3, reps=20):
     """Back-to-back launches of each axis pass between HIP events; algorithmic bytes = 8 B/voxel/pass."""
     from fetalsyngen_amd import kernels as K
@@ -152,7 +188,7 @@ def main():
     from fetalsyngen_amd.generator.augmentation import synthseg as _ss
 
     orig_blur = _ss.RandResample.blur
-    ev = []
+    ev, passes = [], []
 
     def timed_blur(output, stds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -160,6 +196,7 @@ def main():
         r = orig_blur(output, stds)
         e1.record()
         ev.append((e0, e1, int(sum(1 for s in stds if s > 0))))
+        passes.extend((ax, int(np.ceil(3 * s))) for ax, s in enumerate(stds) if s > 0)
         return r
 
     _ss.RandResample.blur = staticmethod(timed_blur)
@@ -168,6 +205,7 @@ def main():
         step(i, False)
     torch.cuda.synchronize()
     ev.clear()
+    passes.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -208,7 +246,8 @@ def main():
                    "parallelism": f"{world} independent replicas (no collective)"},
         "roofline": {"bound": "hbm", "kernel": "blur axis pass (fsg_blur_axis_taps_host_f32)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": blur_traffic_per_launch(passes, args.size),
                      "us_per_launch": round(blur_us, 2), "launches_timed": launches,
                      "algorithmic_bytes_per_launch": 8 * nvox},
     }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "fsg_randn_f32": [P, SZ, U64, U64, P],
     "fsg_gmm_sample_u8": [P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_gmm_sample_i64": [P, SZ, P, P, I, P, U64, U64, P, P],
+    "fsg_gmm_sample_u8x4": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_label_stats_u8": [P, P, SZ, I, P, P, P, P],
     "fsg_zoom3d_f32": [P, I, I, I, I, P, P, P, P, I, I, I, P],
     "fsg_resample_noise_f32": [P, I, I, I, P, P, P, P, I, I, I, I, P, U64, U64, F, P],
@@ -69,6 +70,7 @@ SIGNATURES = {
     "fsg_minmax_init": [P, I, I, P],
     "fsg_deform_rows_f32": [C.POINTER(Deform), C.POINTER(Epilogue), P, I, P],
     "fsg_coords_minmax_f32": [C.POINTER(Deform), P, P],
+    "fsg_coords_floormin_f32": [C.POINTER(Deform), P, P],
     "fsg_coords_f32": [C.POINTER(Deform), P, P, P, P, P],
     "fsg_warp_f32": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
     "fsg_warp_f32_u8": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],

@@ -242,43 +242,75 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 __global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, float* __restrict__ rows, int stride) {
   const int nf = D.field ? 3 * D.f2 : 0;
   const int need = nf + (E.bias ? E.b2 : 0);
-  const size_t total = (size_t)D.n0 * D.n1 * need;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const int e = (int)(t % need);
-    const int r = (int)(t / need);
-    const int i = r / D.n1, j = r - i * D.n1;
-    float v;
-    if (e < nf) {
-      const fsg_tap a = D.tx[i], b = D.ty[j];
-      const int c = e / D.f2, zs = e - c * D.f2;
-      const int o = zs * 3 + c;
-      const float* g = D.field;
-      const float f00 = g[(((size_t)a.lo * D.f1 + b.lo) * D.f2) * 3 + o];
-      const float f10 = g[(((size_t)a.hi * D.f1 + b.lo) * D.f2) * 3 + o];
-      const float f01 = g[(((size_t)a.lo * D.f1 + b.hi) * D.f2) * 3 + o];
-      const float f11 = g[(((size_t)a.hi * D.f1 + b.hi) * D.f2) * 3 + o];
-      v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
-    } else {
-      const fsg_tap a = E.bx[i], b = E.by[j];
-      const int zs = e - nf;
-      const float* g = E.bias;
-      const float f00 = g[((size_t)a.lo * E.b1 + b.lo) * E.b2 + zs];
-      const float f10 = g[((size_t)a.hi * E.b1 + b.lo) * E.b2 + zs];
-      const float f01 = g[((size_t)a.lo * E.b1 + b.hi) * E.b2 + zs];
-      const float f11 = g[((size_t)a.hi * E.b1 + b.hi) * E.b2 + zs];
-      v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
-    }
-    rows[(size_t)r * stride + e] = v;
+  const int i = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (j, e) of this x plane
+  if (t >= D.n1 * need) return;
+  const int j = t / need, e = t - j * need;
+  float v;
+  if (e < nf) {
+    const fsg_tap a = D.tx[i], b = D.ty[j];
+    const int c = e / D.f2, zs = e - c * D.f2;
+    const int o = zs * 3 + c;
+    const float* g = D.field;
+    const float f00 = g[((a.lo * D.f1 + b.lo) * D.f2) * 3 + o];
+    const float f10 = g[((a.hi * D.f1 + b.lo) * D.f2) * 3 + o];
+    const float f01 = g[((a.lo * D.f1 + b.hi) * D.f2) * 3 + o];
+    const float f11 = g[((a.hi * D.f1 + b.hi) * D.f2) * 3 + o];
+    v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
+  } else {
+    const fsg_tap a = E.bx[i], b = E.by[j];
+    const int zs = e - nf;
+    const float* g = E.bias;
+    const float f00 = g[(a.lo * E.b1 + b.lo) * E.b2 + zs];
+    const float f10 = g[(a.hi * E.b1 + b.lo) * E.b2 + zs];
+    const float f01 = g[(a.lo * E.b1 + b.hi) * E.b2 + zs];
+    const float f11 = g[(a.hi * E.b1 + b.hi) * E.b2 + zs];
+    v = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
+  }
+  rows[((size_t)i * D.n1 + j) * stride + e] = v;
+}
+
+// ---- floor(min) of the clamped coordinates with a boundary shortcut --------------------------------------
+// Only floor(min) per axis is consumed downstream (margin subtraction, affine_nonrigid.py:350-358).  The
+// coordinates are clamped to [0, n-1], so as soon as ONE voxel has a coordinate < 1 on an axis, that axis'
+// floor(min) is 0 whatever the other voxels do.  In practice such voxels sit on the faces of the grid: pass 1
+// evaluates the six faces only (2.3 % of a 256^3 grid); pass 2 (all voxels) runs only for the rare
+// deformations where some axis is still unresolved -- every block of it first checks the three keys and
+// exits when all are below key(1.0).  The result has the same floor as the exact minimum.
+__global__ __launch_bounds__(256) void coords_faces_min_kernel(FsgDeformK D, int32_t* __restrict__ mm3) {
+  const int n0 = D.n0, n1 = D.n1, n2 = D.n2;
+  const int fa = n1 * n2, fb = n0 * n2, fc = n0 * n1;
+  const int total = 2 * (fa + fb + fc);
+  float lo[3] = {INFINITY, INFINITY, INFINITY};
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    int i, j, k, u = t;
+    if (u < 2 * fa) { i = (u >= fa) ? n0 - 1 : 0; u %= fa; j = u / n2; k = u - j * n2; }
+    else if ((u -= 2 * fa) < 2 * fb) { j = (u >= fb) ? n1 - 1 : 0; u %= fb; i = u / n2; k = u - i * n2; }
+    else { u -= 2 * fb; k = (u >= fc) ? n2 - 1 : 0; u %= fc; i = u / n1; j = u - i * n1; }
+    float x, y, z;
+    fsg_position(D, i, j, k, x, y, z);
+    lo[0] = fminf(lo[0], x);
+    lo[1] = fminf(lo[1], y);
+    lo[2] = fminf(lo[2], z);
+  }
+  __shared__ float red[3][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float l = fsg_wave_min(lo[a]);
+    if (lane == 0) red[a][wave] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    float v = red[a][0];
+    for (int w = 1; w < 4; ++w) v = fminf(v, red[a][w]);
+    fsg_atomic_min_key(&mm3[a], v);
   }
 }
 
 constexpr int WARP_ROWS_PER_WAVE = 4;
 
-// Four voxels of one lane (k = kbase + 64*q), branch-free: every address is in range by construction
-// (positions are clamped to [0, n-1] before the margin subtraction, which only lowers them towards 0), so
-// the 16 pair-gathers + 4 nearest gathers are issued back to back and their latencies overlap; the strict
-// ">0" validity rule of the reference is applied as a select afterwards.  Arithmetic per voxel is identical
-// to sample_linear / sample_nearest.
 // Tuning knobs measured on MI355X (tools/kernel_bench.py, 256^3, rot 12 deg): batch 2 + skipping the gathers
 // of voxels that sample outside the volume is the fastest of {1,2,4} x {skip, no skip} for the full kernel.
 #ifndef FSG_WARP_BATCH
@@ -474,8 +506,16 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
   }
 }
 
+template <bool MIN_ONLY>
 __global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, int32_t* __restrict__ mm6,
                                                                  int rows_per_block) {
+  if (MIN_ONLY) {  // floor(min) already known to be 0 on every axis: nothing to add (block-uniform exit)
+    const int32_t one = fsg_f2key(1.0f);
+    const int32_t k0 = __hip_atomic_load(&mm6[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t k1 = __hip_atomic_load(&mm6[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t k2 = __hip_atomic_load(&mm6[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k0 < one && k1 < one && k2 < one) return;
+  }
   __shared__ float sm_all[4][ROWCAP];
   __shared__ float red[6][4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -537,7 +577,7 @@ __global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, i
     float v = red[a][0];
     for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[a][w]) : fmaxf(v, red[a][w]);
     if (a < 3) fsg_atomic_min_key(&mm6[a], v);
-    else fsg_atomic_max_key(&mm6[a], v);
+    else if (!MIN_ONLY) fsg_atomic_max_key(&mm6[a], v);
   }
 }
 
@@ -665,10 +705,9 @@ int fsg_deform_rows_f32(const fsg_deform* d, const fsg_epilogue* epi, float* row
   const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
   if (!rows || row_stride < need) return FSG_E_BADARG;
   if (need == 0) return 0;
-  size_t blocks = ((size_t)D.n0 * D.n1 * need + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(deform_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), D, E, rows,
-                     row_stride);
+  if (D.n0 > 65535) return FSG_E_TOOBIG;
+  const dim3 grid((unsigned)((D.n1 * need + 255) / 256), (unsigned)D.n0);
+  hipLaunchKernelGGL(deform_rows_kernel, grid, dim3(256), 0, fsg_stream(stream), D, E, rows, row_stride);
   FSG_RETURN_LAUNCH();
 }
 
@@ -682,11 +721,34 @@ int fsg_coords_minmax_f32(const fsg_deform* d, int32_t* mm6, void* stream) {
     int grid = (rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048;
     const int rpb = (rows + grid - 1) / grid;
     grid = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(coords_minmax_rows_kernel, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm6, rpb);
+    hipLaunchKernelGGL(coords_minmax_rows_kernel<false>, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm6, rpb);
     FSG_RETURN_LAUNCH();
   }
   const int grid = rows < 2048 ? rows : 2048;
   hipLaunchKernelGGL(coords_minmax_kernel, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm6);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_coords_floormin_f32(const fsg_deform* d, int32_t* mm3, void* stream) {
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  if (!mm3) return FSG_E_BADARG;
+  hipStream_t st = fsg_stream(stream);
+  const int faces = 2 * (D.n1 * D.n2 + D.n0 * D.n2 + D.n0 * D.n1);
+  int g1 = (faces + 255) / 256;
+  if (g1 > 1024) g1 = 1024;
+  hipLaunchKernelGGL(coords_faces_min_kernel, dim3(g1), dim3(256), 0, st, D, mm3);
+  const int rows = D.n0 * D.n1;
+  if ((D.field ? 3 * D.f2 : 0) <= ROWCAP) {
+    int grid = (rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048;
+    const int rpb = (rows + grid - 1) / grid;
+    grid = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(coords_minmax_rows_kernel<true>, dim3(grid), dim3(256), 0, st, D, mm3, rpb);
+  } else {
+    // very large coarse grids: exact per-voxel pass (writes the maxima after the three minima too)
+    return FSG_E_TOOBIG;
+  }
   FSG_RETURN_LAUNCH();
 }
 

@@ -50,6 +50,62 @@ __global__ __launch_bounds__(256) void gmm_kernel(const LT* __restrict__ labels,
   }
 }
 
+// K1 with the seed map given as its (up to) four per-meta-label volumes (rand_gmm.py:90-99 sums them):
+// the byte-wise sum is formed on the fly from 32-bit words (4 voxels), supports are disjoint so no byte
+// overflows into its neighbour.  Saves three full-volume add launches and the summed volume.
+__global__ __launch_bounds__(256) void gmm_x4_kernel(const uint8_t* __restrict__ l0, const uint8_t* __restrict__ l1,
+                                                     const uint8_t* __restrict__ l2, const uint8_t* __restrict__ l3,
+                                                     size_t n, const float* __restrict__ mus,
+                                                     const float* __restrict__ sigmas, int ntab,
+                                                     const float* __restrict__ noise, uint64_t seed,
+                                                     uint64_t stream_id, float* __restrict__ out) {
+  __shared__ float s_mu[256], s_sg[256];
+  for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+    s_mu[t] = t < ntab ? mus[t] : 0.f;
+    s_sg[t] = t < ntab ? sigmas[t] : 0.f;
+  }
+  __syncthreads();
+  const size_t nblk = (n + 3) >> 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nblk; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = g << 2;
+    uint32_t w = 0;
+    if (e + 3 < n) {
+      w = *reinterpret_cast<const uint32_t*>(l0 + e);
+      if (l1) w += *reinterpret_cast<const uint32_t*>(l1 + e);
+      if (l2) w += *reinterpret_cast<const uint32_t*>(l2 + e);
+      if (l3) w += *reinterpret_cast<const uint32_t*>(l3 + e);
+    } else {
+      for (int q = 0; q < 4 && e + q < n; ++q) {
+        uint32_t b = l0[e + q];
+        if (l1) b += l1[e + q];
+        if (l2) b += l2[e + q];
+        if (l3) b += l3[e + q];
+        w |= (b & 255u) << (8 * q);
+      }
+    }
+    float z[4];
+    if (noise) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) z[q] = (e + q < n) ? noise[e + q] : 0.f;
+    } else {
+      const float4 r = fsg_randn4(seed, stream_id, (uint64_t)g);
+      z[0] = r.x; z[1] = r.y; z[2] = r.z; z[3] = r.w;
+    }
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l = (int)((w >> (8 * q)) & 255u);
+      const float t = s_mu[l] + s_sg[l] * z[q];
+      v[q] = t < 0.f ? 0.f : t;
+    }
+    if (e + 3 < n) {
+      *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int q = 0; q < 4 && e + q < n; ++q) out[e + q] = v[q];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed,
                                                     uint64_t stream_id) {
   const size_t nblk = (n + 3) >> 2;
@@ -168,6 +224,18 @@ int fsg_randn_f32(float* out, size_t n, uint64_t seed, uint64_t stream_id, void*
 int fsg_gmm_sample_u8(const uint8_t* labels, size_t n, const float* mus, const float* sigmas, int ntab,
                       const float* noise, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
   return launch_gmm<uint8_t>(labels, n, mus, sigmas, ntab, noise, seed, stream_id, out, stream);
+}
+
+int fsg_gmm_sample_u8x4(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                        const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                        uint64_t stream_id, float* out, void* stream) {
+  if (n == 0) return 0;
+  if (!l0 || !mus || !sigmas || !out || ntab <= 0 || ntab > 256) return FSG_E_BADARG;
+  const uintptr_t al = (uintptr_t)l0 | (uintptr_t)l1 | (uintptr_t)l2 | (uintptr_t)l3;
+  if ((al & 3) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
+  hipLaunchKernelGGL(gmm_x4_kernel, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, fsg_stream(stream), l0, l1, l2, l3,
+                     n, mus, sigmas, ntab, noise, seed, stream_id, out);
+  FSG_RETURN_LAUNCH();
 }
 
 int fsg_gmm_sample_i64(const int64_t* labels, size_t n, const float* mus, const float* sigmas, int ntab,

@@ -216,6 +216,116 @@ __global__ __launch_bounds__(256) void zoom1_rows_kernel(ZoomK Z, EpiZ E, int ro
   }
 }
 
+// Software-pipelined variant for sz <= 256 and dz <= 256 (every low-res / full-res size of the 256^3
+// configuration): the wave fetches the taps of ALL its rows with one coalesced load (lane t <- row t),
+// and the four source rows of row t+1 are in flight in registers while row t is blended and emitted, so
+// the dependent chain "table entry -> source rows -> LDS -> output" is paid once per wave, not per row.
+template <int EPI>
+__global__ __launch_bounds__(256) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, int rows_per_block) {
+  __shared__ float sm_all[4][2][256];
+  __shared__ float red[2][4];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float lo = INFINITY, hi = -INFINITY;
+  float mnq = 0.f, den = 1.f, mx = 1.f;
+  if (EPI == EPI_NORM) {
+    mx = fsg_key2f(E.mm_in[1]);
+    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    den = 1.0f - mnq;
+  }
+  const int nb = gridDim.x;
+  const int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int rows = Z.dx * Z.dy;
+  const int r_begin = tile * rows_per_block;
+  const int r_end = min(rows, r_begin + rows_per_block);
+  fsg_tap ck[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = lane + 64 * q;
+    ck[q] = k < Z.dz ? Z.tz[k] : fsg_tap{-1, 0, 0.f, 0.f};
+  }
+  for (int base = r_begin + wave; base < r_end; base += 4 * 64) {  // chunks of 64 rows of this wave
+    const int nw = min(64, (r_end - base + 3) / 4);
+    int4 ta = make_int4(-1, 0, 0, 0), tb = make_int4(-1, 0, 0, 0);
+    if (lane < nw) {
+      const int r = base + 4 * lane;
+      const int i = r / Z.dy, j = r - i * Z.dy;
+      ta = *reinterpret_cast<const int4*>(Z.tx + i);
+      tb = *reinterpret_cast<const int4*>(Z.ty + j);
+    }
+    float cur[4][4], nxt[4][4];
+    fsg_tap a, b, an, bn;
+    auto taps_of = [&](int t, fsg_tap& ra, fsg_tap& rb) {
+      ra.lo = __builtin_amdgcn_readlane(ta.x, t);
+      ra.hi = __builtin_amdgcn_readlane(ta.y, t);
+      ra.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ta.z, t));
+      ra.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ta.w, t));
+      rb.lo = __builtin_amdgcn_readlane(tb.x, t);
+      rb.hi = __builtin_amdgcn_readlane(tb.y, t);
+      rb.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tb.z, t));
+      rb.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tb.w, t));
+    };
+    auto fetch = [&](const fsg_tap& ra, const fsg_tap& rb, float (&v)[4][4]) {
+      if (ra.lo < 0 || rb.lo < 0) return;
+      const float* p[4] = {Z.src + ((size_t)ra.lo * Z.sy + rb.lo) * Z.sz, Z.src + ((size_t)ra.hi * Z.sy + rb.lo) * Z.sz,
+                           Z.src + ((size_t)ra.lo * Z.sy + rb.hi) * Z.sz, Z.src + ((size_t)ra.hi * Z.sy + rb.hi) * Z.sz};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int zs = lane + 64 * c;
+        if (zs < Z.sz) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u][c] = p[u][zs];
+        }
+      }
+    };
+    taps_of(0, a, b);
+    fetch(a, b, cur);
+    for (int t = 0; t < nw; ++t) {
+      if (t + 1 < nw) {
+        taps_of(t + 1, an, bn);
+        fetch(an, bn, nxt);
+      }
+      float* sm = sm_all[wave][t & 1];
+      const bool okr = a.lo >= 0 && b.lo >= 0;
+      if (okr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int zs = lane + 64 * c;
+          if (zs < Z.sz) {
+            const float t0 = fsg_mix(a.w_lo, cur[0][c], a.w_hi, cur[1][c]);
+            const float t1 = fsg_mix(a.w_lo, cur[2][c], a.w_hi, cur[3][c]);
+            sm[zs] = fsg_mix(b.w_lo, t0, b.w_hi, t1);
+          }
+        }
+      }
+      zwave_sync();
+      const size_t row = (size_t)(base + 4 * t) * Z.dz;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        if (k < Z.dz) zoom_emit<EPI>(Z, E, sm, okr, ck[q], row + k, mx, mnq, den, lo, hi);
+      }
+      a = an;
+      b = bn;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[u][c] = nxt[u][c];
+    }
+    zwave_sync();
+  }
+  if (EPI == EPI_MINMAX) {
+    lo = fsg_wave_min(lo);
+    hi = fsg_wave_max(hi);
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+      fsg_atomic_min_key(&E.mm_out[0], lo);
+      fsg_atomic_max_key(&E.mm_out[1], hi);
+    }
+  }
+}
+
 int check(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty, const fsg_tap* tz, int dx,
           int dy, int dz) {
   if (!src || !tx || !ty || !tz) return FSG_E_BADARG;
@@ -234,7 +344,10 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     if (nblk > 2048) nblk = 2048;
     if (nblk >= 8) nblk &= ~7;  // multiple of 8 for the XCD-contiguous tile order
     const int rpb = (rows + nblk - 1) / nblk;
-    hipLaunchKernelGGL(zoom1_rows_kernel<EPI>, dim3(nblk), dim3(256), 0, fsg_stream(stream), Z, E, rpb);
+    if (Z.sz <= 256 && Z.dz <= 256 && !(g_tuning_flags & FSG_TUNE_NO_PREFETCH))
+      hipLaunchKernelGGL(zoom1_rows_pf_kernel<EPI>, dim3(nblk), dim3(256), 0, fsg_stream(stream), Z, E, rpb);
+    else
+      hipLaunchKernelGGL(zoom1_rows_kernel<EPI>, dim3(nblk), dim3(256), 0, fsg_stream(stream), Z, E, rpb);
     FSG_RETURN_LAUNCH();
   }
   const int grid = rows < 4096 ? rows : 4096;

@@ -35,6 +35,14 @@ class SeedBank:
         }
         self._cache = {}
 
+    def parts(self, mlabel2subclusters: dict):
+        """The selected per-meta-label volumes (disjoint supports); `fsg_gmm_sample_u8x4` sums them on the fly."""
+        return [self.vol[n][m] for m, n in sorted(mlabel2subclusters.items())]
+
+    @property
+    def shape(self):
+        return tuple(next(iter(next(iter(self.vol.values())).values())).shape)
+
     def combined(self, mlabel2subclusters: dict) -> torch.Tensor:
         key = tuple(sorted(mlabel2subclusters.items()))
         hit = self._cache.get(key)

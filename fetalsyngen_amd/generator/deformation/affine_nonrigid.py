@@ -143,9 +143,10 @@ class SpatialDeformation:
             return image, segmentation, output
         if spec is None:
             spec = self.make_spec(plan, output.shape, flip_in_kernel=True).build()
-        spec.prepare_rows(bias, bias_tabs)
+        if not spec.c.rows:
+            spec.prepare_rows(bias, bias_tabs)
         if mm6 is None:
-            mm6 = K.coords_minmax(spec)
+            mm6 = K.coords_floormin(spec)
         seg = segmentation.to(self.device).contiguous()
         if seg.dtype not in (torch.float32, torch.uint8):
             seg = seg.float()

@@ -165,16 +165,17 @@ class FetalSynthGen:
         ig, sd = self.intensity_generator, self.spatial_deform
         with _rng.use(self.rng):
             # ---------------- host: every random draw, in the reference's order ----------------
-            labels, gmm_plan, selected_seeds = None, None, {}
+            labels, label_parts, gmm_plan, selected_seeds = None, None, None, {}
             if seeds is not None:
                 gs = genparams.get("selected_seeds", {})
-                if hasattr(seeds, "combined"):  # device-resident seed bank (fetalsyngen_amd.data.SeedBank)
+                if hasattr(seeds, "parts") and ig.meta_labels <= 4:  # device-resident SeedBank
                     m2s = ig.draw_subclusters(gs)
-                    labels, selected_seeds = seeds.combined(m2s), {"mlabel2subclusters": m2s}
+                    label_parts, selected_seeds = seeds.parts(m2s), {"mlabel2subclusters": m2s}
+                    shape = tuple(label_parts[0].shape)
                 else:
                     labels, selected_seeds = ig.load_seeds(seeds=seeds, genparams=gs)
-                gmm_plan = ig.plan_intensities(tuple(labels.shape), genparams.get("seed_intensities", {}))
-                shape = tuple(labels.shape)
+                    shape = tuple(labels.shape)
+                gmm_plan = ig.plan_intensities(shape, genparams.get("seed_intensities", {}))
             else:
                 if image is None:
                     raise ValueError(
@@ -212,12 +213,16 @@ class FetalSynthGen:
             seed_intensities = {}
             if gmm_plan is not None:
                 mus, sigmas = f32_view(gm_off[0], (gm_off[2],)), f32_view(gm_off[1], (gm_off[2],))
-                if labels.dtype not in (torch.uint8, torch.int64):
-                    labels = labels.long()
-                labels = labels.to(dev).contiguous()
                 f = gmm_plan.field
                 z = f.device_tensor(dev) if f.host is not None else None
-                output = K.gmm_sample(labels, mus, sigmas, noise=z, seed=f.seed or 0, stream_id=f.stream_id)
+                if label_parts is not None:
+                    output = K.gmm_sample_parts(label_parts, mus, sigmas, noise=z, seed=f.seed or 0,
+                                                stream_id=f.stream_id)
+                else:
+                    if labels.dtype not in (torch.uint8, torch.int64):
+                        labels = labels.long()
+                    labels = labels.to(dev).contiguous()
+                    output = K.gmm_sample(labels, mus, sigmas, noise=z, seed=f.seed or 0, stream_id=f.stream_id)
                 seed_intensities = {"mus": mus, "sigmas": sigmas}
             else:
                 output = self._intensity_prior(image)
@@ -225,10 +230,14 @@ class FetalSynthGen:
             bias_dev = f32_view(bias_off, tuple(bplan.grid.shape)) if bplan.active else None
             gam = float(g) if g is not None else None
             image = image.to(dev) if image is not None else None
+            # one init launch for every min/max key of the sample: [min x,y,z | zoom min] [zoom max | unused x3]
+            mm8 = K.new_minmax(dev, 4, 4)
             if dplan.active:
                 spec = sb.build()
+                spec.prepare_rows(bias_dev, bias_tabs)
                 image, segmentation, output = sd.run(dplan, image, segmentation, output, spec=spec,
-                                                     gamma=gam, bias=bias_dev, bias_tabs=bias_tabs)
+                                                     mm6=K.coords_floormin(spec, mm8), gamma=gam, bias=bias_dev,
+                                                     bias_tabs=bias_tabs)
             else:
                 segmentation = segmentation.to(dev)
                 if gam is not None:
@@ -245,7 +254,8 @@ class FetalSynthGen:
                 low = K.resample_noise(blurred, rs_tabs, noise_std=nplan.std32 if nplan.active else 0.0, noise=z,
                                        seed=(f.seed if (f is not None and f.host is None) else None),
                                        stream_id=f.stream_id if f is not None else 0)
-                output = K.zoom_normalise(low, back_tabs, K.zoom_minmax(low, back_tabs), mode=1 if fuse_scale else 0)
+                mm2 = K.zoom_minmax(low, back_tabs, mm=mm8[3:5])
+                output = K.zoom_normalise(low, back_tabs, mm2, mode=1 if fuse_scale else 0)
             else:
                 if nplan.active:
                     output = K.add_noise(output, nplan.std32, noise=z, seed=f.seed or 0, stream_id=f.stream_id)

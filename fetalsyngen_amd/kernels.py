@@ -135,6 +135,26 @@ def gmm_sample(labels, mus, sigmas, noise=None, seed=0, stream_id=0) -> torch.Te
     return out
 
 
+def gmm_sample_parts(parts, mus, sigmas, noise=None, seed=0, stream_id=0) -> torch.Tensor:
+    """GMM draw from the per-meta-label seed volumes (uint8, disjoint supports) without summing them."""
+    parts = [p for p in parts if p is not None]
+    if not 1 <= len(parts) <= 4:
+        raise ValueError("1..4 label volumes expected")
+    _need_gpu(*parts, mus, sigmas, noise)
+    for p in parts:
+        if p.dtype != torch.uint8 or p.shape != parts[0].shape:
+            raise TypeError("label parts must be uint8 volumes of one shape")
+    _f32(mus), _f32(sigmas)
+    ntab = int(mus.numel())
+    if noise is not None and _f32(noise).numel() != parts[0].numel():
+        raise ValueError("noise must match labels")
+    out = torch.empty(parts[0].shape, dtype=F32, device=parts[0].device)
+    ptrs = [_p(p) for p in parts] + [C.c_void_p(0)] * (4 - len(parts))
+    _lib.check(_lib.load().fsg_gmm_sample_u8x4(*ptrs, out.numel(), _p(mus), _p(sigmas), ntab, _p(noise), seed,
+                                               stream_id, _p(out), _stream(out)), "fsg_gmm_sample_u8x4")
+    return out
+
+
 def label_stats(labels_u8, values, nlabels: int):
     """(count int64[nlabels], mean f64, var f64) per label -- wave-level reductions on the device."""
     _need_gpu(labels_u8, values)
@@ -197,10 +217,11 @@ def resample_noise(src, tabs: DeviceTables, noise_std=0.0, noise=None, seed=None
     return dst
 
 
-def zoom_minmax(src, tabs: DeviceTables) -> torch.Tensor:
+def zoom_minmax(src, tabs: DeviceTables, mm=None) -> torch.Tensor:
     sx, sy, sz = _zoom_args(src, tabs)
     dx, dy, dz = tabs.lengths
-    mm = new_minmax(src.device)
+    if mm is None:
+        mm = new_minmax(src.device)
     tx, ty, tz = tabs.ptrs
     _lib.check(_lib.load().fsg_zoom3d_minmax_f32(_p(src), sx, sy, sz, tx, ty, tz, dx, dy, dz, _p(mm), _stream(src)),
                "fsg_zoom3d_minmax_f32")
@@ -287,6 +308,17 @@ def coords_minmax(spec: DeformSpec) -> torch.Tensor:
     mm6 = new_minmax(spec.device, 3, 3)
     _lib.check(_lib.load().fsg_coords_minmax_f32(C.byref(spec.c), _p(mm6), _stream(mm6)), "fsg_coords_minmax_f32")
     return mm6
+
+
+def coords_floormin(spec: DeformSpec, mm3=None) -> torch.Tensor:
+    """Keys whose floor is floor(min coordinate) per axis (faces first, full pass only if needed)."""
+    if mm3 is None:
+        mm3 = new_minmax(spec.device, 3, 0)
+    rc = _lib.load().fsg_coords_floormin_f32(C.byref(spec.c), _p(mm3), _stream(mm3))
+    if rc == _lib.E_TOOBIG:
+        return coords_minmax(spec)
+    _lib.check(rc, "fsg_coords_floormin_f32")
+    return mm3
 
 
 def coords(spec: DeformSpec, mm6):

@@ -70,6 +70,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_GENERIC_WARP 1  /* per-voxel field evaluation instead of the row-wise LDS kernels */
 #define FSG_TUNE_PRECISE_MATH 2  /* OCML powf/expf in the gamma/bias epilogue instead of v_log/v_exp */
 #define FSG_TUNE_GENERIC_ZOOM 4  /* per-voxel 8-tap zoom instead of the row-wise LDS kernels */
+#define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
 int fsg_set_tuning(int flags);
 
 /* ---- RNG ------------------------------------------------------------------------------------ */
@@ -86,6 +87,11 @@ int fsg_gmm_sample_u8(const uint8_t* labels, size_t n, const float* mus, const f
                       const float* noise, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 int fsg_gmm_sample_i64(const int64_t* labels, size_t n, const float* mus, const float* sigmas, int ntab,
                        const float* noise, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* Same with the seed map given as the per-meta-label volumes load_seeds would sum (rand_gmm.py:90-99):
+ * label = l0 + l1 + l2 + l3 formed on the fly (l1..l3 may be NULL).  Pointers 4-byte aligned, out 16-byte. */
+int fsg_gmm_sample_u8x4(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                        const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                        uint64_t stream_id, float* out, void* stream);
 
 /* Per-label count / sum / sum of squares of `values` (wave-level reductions); accumulates into the
  * caller-zeroed outputs.  Used to validate device-RNG GMM draws against mus/sigmas. */
@@ -128,6 +134,12 @@ int fsg_deform_rows_f32(const fsg_deform* d_host, const struct fsg_epilogue* epi
 /* min / max over the grid of the clamped coordinates, before margin subtraction; mm6 = {min x,y,z,
  * max x,y,z} as ordered int32 keys.  Reads only the coarse field. */
 int fsg_coords_minmax_f32(const fsg_deform* d_host, int32_t* mm6, void* stream);
+/* What the warp actually needs: keys in mm3[0..2] whose floor equals floor(min) of the clamped coordinate
+ * per axis (caller initialises them with fsg_minmax_init(mm3, 3, 0)).  Evaluates the six faces of the grid
+ * first; the full pass exits immediately once every axis has a voxel below 1 (coordinates are >= 0, so
+ * floor(min) is then 0).  Usable wherever fsg_warp_* takes `mm6` (only entries 0..2 are read there).
+ * Returns FSG_E_TOOBIG for coarse grids beyond the row kernels' capacity: use fsg_coords_minmax_f32. */
+int fsg_coords_floormin_f32(const fsg_deform* d_host, int32_t* mm3, void* stream);
 /* Materialise xx2, yy2, zz2 (after subtracting floor(min)) -- the tensors
  * SpatialDeformation.generate_deformation_and_flip returns.  mm6 from fsg_coords_minmax_f32. */
 int fsg_coords_f32(const fsg_deform* d_host, const int32_t* mm6, float* xx, float* yy, float* zz, void* stream);

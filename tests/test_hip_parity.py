@@ -467,7 +467,7 @@ def test_rowwise_kernels_equal_per_voxel_kernels(K, golden):
     src = (rs.rand(37, 29, 41) * 255).astype(np.float32)
     tabs, _ = T.zoom_tables(src.shape, np.array((64, 80, 96)) / np.array(src.shape))
     outs = []
-    for flags in (0, 4):
+    for flags in (0, 4, 8):
         prev = lib.fsg_set_tuning(flags)
         try:
             dt = K.DeviceTables(tabs, DEV)
@@ -479,6 +479,47 @@ def test_rowwise_kernels_equal_per_voxel_kernels(K, golden):
             outs.append([host(v) for v in (z, mm, n0, n1, zn)])
         finally:
             lib.fsg_set_tuning(prev)
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
     assert np.array_equal(outs[0][0], O.linear_zoom(t(src), np.array((64, 80, 96)) / np.array(src.shape)).numpy())
+
+
+def test_floormin_shortcut_has_the_exact_floor(K, golden):
+    """fsg_coords_floormin_f32 (faces first, conditional full pass) vs the golden margins, including the
+    engineered case whose minima are far from 0 (the full pass must then run and be exact)."""
+    g = golden("deform_image")
+    for i in range(int(g["ncases"])):
+        spec, shape = _spec_from_golden(K, g, i)
+        for ws in (False, True):
+            if ws:
+                spec.prepare_rows()
+            mm3 = K.coords_floormin(spec)
+            lo = [int(np.floor(K.key_to_float(k))) for k in host(mm3)[:3]]
+            assert lo == list(g[f"margins_{i}"][:3]), (i, ws)
+    assert list(g["margins_1"][:3]) != [0, 0, 0]
+    # and the warp fed by it equals the warp fed by the exact min/max
+    spec, shape = _spec_from_golden(K, g, 1)
+    img = dev((np.random.RandomState(2).rand(*shape) * 255).astype(np.float32))
+    a, _ = K.warp(spec, K.coords_floormin(spec), src_lin=img)
+    b, _ = K.warp(spec, K.coords_minmax(spec), src_lin=img)
+    assert torch.equal(a, b)
+
+
+def test_gmm_from_label_parts_equals_gmm_of_the_sum(K):
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import combined_seed_labels, make_seed_volumes
+
+    for shape in [(32, 32, 32), (17, 9, 7)]:  # second: size not a multiple of 4 (ragged tail)
+        seg, seeds = make_seed_volumes(shape)
+        bank = SeedBank(seeds, DEV)
+        m2s = {1: 3, 2: 6, 3: 1, 4: 4}
+        mus = dev(np.linspace(20, 220, 50, dtype=np.float32))
+        sig = dev(np.linspace(5, 25, 50, dtype=np.float32))
+        a = K.gmm_sample_parts(bank.parts(m2s), mus, sig, seed=5, stream_id=1)
+        comb = dev(combined_seed_labels(seeds, m2s))
+        b = K.gmm_sample(comb, mus, sig, seed=5, stream_id=1)
+        assert torch.equal(a, b)
+        assert torch.equal(bank.combined(m2s), comb)
+        z = torch.randn(shape).to(DEV)
+        assert torch.equal(K.gmm_sample_parts(bank.parts(m2s), mus, sig, noise=z), K.gmm_sample(comb, mus, sig, noise=z))
