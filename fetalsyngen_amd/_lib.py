@@ -74,6 +74,7 @@ SIGNATURES = {
     "fsg_coords_f32": [C.POINTER(Deform), P, P, P, P, P],
     "fsg_warp_f32": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
     "fsg_warp_f32_u8": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
+    "fsg_warp_f32_u8_to_f32": [C.POINTER(Deform), P, P, P, P, P, C.POINTER(Epilogue), P],
     "fsg_interp3d_f32": [P, I, I, I, P, P, P, SZ, I, F, P, P],
     "fsg_gamma_f32": [P, SZ, F, P, P],
     "fsg_bias_mul_f32": [P, I, I, I, P, I, I, I, P, P, P, P, P],

@@ -457,10 +457,32 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
                                                         LT* __restrict__ out_nn, EpiK E) {
   __shared__ float sm_all[4][2][ROWCAP];  // per wave, double buffered
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
+  // Row -> wave mapping (FSG_WARP_MAP).  An L1-missing cache line costs ~10.7 cycles of the CU's fill path
+  // (profiles/r01_gather_cost_ubench.txt), so the four waves of a block should gather from ADJACENT source
+  // rows at the same time: 0 = wave w owns rows 4w..4w+3 (no sharing), 1 = wave w owns rows w, w+4, w+8,
+  // w+12 (the block sweeps 4 adjacent rows per step), 2 = 2x2 patches of (x,y) rows.
+#ifndef FSG_WARP_MAP
+#define FSG_WARP_MAP 1
+#endif
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
+#if FSG_WARP_MAP == 2
+  const int tiles_j = (D.n1 + 2 * WARP_ROWS_PER_WAVE - 1) / (2 * WARP_ROWS_PER_WAVE);
+  const int i = min(2 * (tile / tiles_j) + (wave >> 1), D.n0 - 1);
+  const bool dead_i = 2 * (tile / tiles_j) + (wave >> 1) >= D.n0;
+  const int jbase = (tile % tiles_j) * (2 * WARP_ROWS_PER_WAVE) + (wave & 1);
+  const int jstep = 2;
+#else
+  const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
   const int i = tile / tiles_j;
+  const bool dead_i = false;
+#if FSG_WARP_MAP == 1
+  const int jbase = (tile - i * tiles_j) * (4 * WARP_ROWS_PER_WAVE) + wave;
+  const int jstep = 4;
+#else
   const int jbase = (tile - i * tiles_j) * (4 * WARP_ROWS_PER_WAVE) + wave * WARP_ROWS_PER_WAVE;
+  const int jstep = 1;
+#endif
+#endif
   const Margins m = load_margins(mm6);
   const int nf = D.field ? 3 * D.f2 : 0;
   const int need = nf + (E.bias ? E.b2 : 0);
@@ -477,15 +499,16 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
     ck[q] = D.field ? D.tz[k] : none;
     cbk[q] = E.bias ? E.bz[k] : none;
   }
+  if (dead_i) return;
   if (jbase < D.n1 && need) stage_row(D, E, i, jbase, nf, need, ax, abx, sm_all[wave][0], lane);
   for (int r = 0; r < WARP_ROWS_PER_WAVE; ++r) {
-    const int j = jbase + r;
+    const int j = jbase + r * jstep;
     if (j >= D.n1) break;
     const float* sm = sm_all[wave][r & 1];
     wave_lds_sync();
     // prefetch the next row's coarse values into the other buffer while this row's gathers are in flight
-    if (r + 1 < WARP_ROWS_PER_WAVE && j + 1 < D.n1 && need)
-      stage_row(D, E, i, j + 1, nf, need, ax, abx, sm_all[wave][(r + 1) & 1], lane);
+    if (r + 1 < WARP_ROWS_PER_WAVE && j + jstep < D.n1 && need)
+      stage_row(D, E, i, j + jstep, nf, need, ax, abx, sm_all[wave][(r + 1) & 1], lane);
     const size_t row = ((size_t)i * D.n1 + j) * D.n2;
     if (cached) {
       warp_emit4<LT, HAS_LIN, HAS_NN, FAST>(D, E, m, sm, nf, i, j, lane, ck, cbk, row, src_lin, out_lin, src_nn,
@@ -503,6 +526,53 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
                                               src_nn, out_nn);
       }
     }
+  }
+}
+
+// ---- patch variant: 16 waves sweep a 4 x 4 patch of adjacent rows in lockstep ----------------------------
+// Cost model (profiles/r01_gather_cost_ubench.txt): a gather costs ~10.7 cycles of the CU's fill path per
+// 128-B line that misses L1, whatever its width.  Output rows (i..i+3, j..j+3) read source rows that
+// overlap almost entirely (their 2x2 neighbourhoods interleave), so when the 16 waves of ONE workgroup
+// advance through z together -- one 64-voxel chunk per wave per step, a barrier per step -- a line missed
+// by one wave is an L1 hit for the others.  Same per-voxel arithmetic as the row kernel (warp_emitN).
+constexpr int PATCH = 4;
+constexpr int PATCH_ROWCAP = 128;
+
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
+__global__ __launch_bounds__(1024) void warp_patch_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+                                                          const float* __restrict__ src_lin,
+                                                          float* __restrict__ out_lin,
+                                                          const LT* __restrict__ src_nn, LT* __restrict__ out_nn,
+                                                          EpiK E) {
+  __shared__ float sm_all[PATCH * PATCH][PATCH_ROWCAP];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tiles_j = (D.n1 + PATCH - 1) / PATCH;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int i_raw = (tile / tiles_j) * PATCH + (wave >> 2), j_raw = (tile % tiles_j) * PATCH + (wave & 3);
+  const bool live_row = i_raw < D.n0 && j_raw < D.n1;
+  const int i = min(i_raw, D.n0 - 1), j = min(j_raw, D.n1 - 1);
+  const Margins m = load_margins(mm6);
+  const int nf = D.field ? 3 * D.f2 : 0;
+  const int need = nf + (E.bias ? E.b2 : 0);
+  const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
+  float* sm = sm_all[wave];
+  if (need) {
+    const bool onfly = D.rows == nullptr;
+    const fsg_tap ax = (onfly && D.field) ? uniform_tap(D.tx, i) : none;
+    const fsg_tap abx = (onfly && E.bias) ? uniform_tap(E.bx, i) : none;
+    stage_row(D, E, i, j, nf, need, ax, abx, sm, lane);
+  }
+  wave_lds_sync();
+  const size_t row = ((size_t)i * D.n1 + j) * D.n2;
+  for (int kb = 0; kb < D.n2; kb += FSG_WAVE) {
+    fsg_tap ck[4] = {none, none, none, none}, cbk[4] = {none, none, none, none};
+    const int k = min(kb + lane, D.n2 - 1);
+    if (D.field) ck[0] = D.tz[k];
+    if (E.bias) cbk[0] = E.bz[k];
+    if (live_row)
+      warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, 1>(D, E, m, sm, nf, i, j, kb + lane, ck, cbk, row, src_lin, out_lin,
+                                                  src_nn, out_nn);
+    __syncthreads();  // keep the 16 waves on the same z chunk: bounded L1 working set, shared misses
   }
 }
 
@@ -607,6 +677,327 @@ __global__ __launch_bounds__(256) void warp_kernel(FsgDeformK D, const int32_t* 
   }
 }
 
+// =================================================================================================
+// Brick warp kernel: LDS staging of the source bounding box.
+//
+// A block of 256 threads produces an 8 x 8 x 16 brick of the output grid (4 consecutive z per thread):
+//   0. the brick's 8+8+16 table entries and the <= 4^3 coarse-grid nodes it touches go to LDS;
+//   1. every thread evaluates the sampling position of its 4 voxels (reference operation order) and the
+//      block reduces the integer bounding box of all 2x2x2 neighbourhoods (wave shuffles -> LDS atomics);
+//   2. the bounding box of the intensity volume (and of the uint8 label volume) is copied to LDS with
+//      coalesced 16-byte loads -- every source cache line is fetched once per brick instead of once per
+//      gather instruction that touches it (profiles/r01_pmc_warp.md);
+//   3. the trilinear neighbourhoods and the nearest label are read from LDS, blended in the reference's
+//      order, gamma/bias applied, and 4 voxels are stored with one 16-byte store.
+// Bricks whose box does not fit (extreme deformations) or whose coarse window exceeds 4 nodes per axis take
+// the same arithmetic through direct global gathers.  Results are bit-identical to the other warp kernels.
+// STATUS (r01): correct but not yet faster -- 255-265 us vs 175 us for the patch kernel at 256^3: with
+// 48 KiB of LDS only 3 workgroups fit a CU and each brick is a chain of 2 dependent global round trips
+// + 3 barriers, and an 8x8x16 brick's box is ~7x its own volume.  Opt-in via FSG_TUNE_BRICK; the plan in
+// DESIGN.md section 7 (persistent workgroups that prefetch the next brick's box) builds on this kernel.
+// =================================================================================================
+constexpr int BRI = 8, BRJ = 8, BRK = 16;
+constexpr int BR_CAP = 9216;   // floats of LDS for the intensity box (36 KiB)
+constexpr int BR_W = 4;        // coarse nodes per axis held in LDS
+
+struct BrickLds {
+  float box[BR_CAP];
+  uint32_t lab[BR_CAP / 4];
+  float nodes_f[BR_W * BR_W * BR_W * 3];
+  float nodes_b[BR_W * BR_W * BR_W];
+  fsg_tap tap[32];   // [0,8) x, [8,16) y, [16,32) z of the displacement tables
+  fsg_tap btap[32];  // same for the bias tables
+  int bb[6];         // min x,y,z, max x,y,z of the neighbourhoods
+};
+
+__device__ __forceinline__ float sel4(const float (&u)[BR_W], int idx) {
+  float r = u[0];
+  r = idx == 1 ? u[1] : r;
+  r = idx == 2 ? u[2] : r;
+  r = idx == 3 ? u[3] : r;
+  return r;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, FSG_WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, FSG_WAVE));
+  return v;
+}
+
+// x/y interpolation of the LDS node window for the nodes zs = 0..nzw-1 of one channel
+template <int NCH>
+__device__ __forceinline__ void window_xy(const float* nodes, int nyw, int nzw, int ch, const fsg_tap& a, int alo,
+                                          int ahi, const fsg_tap& b, int blo, int bhi, float (&u)[BR_W]) {
+#pragma unroll
+  for (int zs = 0; zs < BR_W; ++zs) {
+    u[zs] = 0.f;
+    if (zs < nzw) {
+      const float f00 = nodes[((alo * nyw + blo) * nzw + zs) * NCH + ch];
+      const float f10 = nodes[((ahi * nyw + blo) * nzw + zs) * NCH + ch];
+      const float f01 = nodes[((alo * nyw + bhi) * nzw + zs) * NCH + ch];
+      const float f11 = nodes[((ahi * nyw + bhi) * nzw + zs) * NCH + ch];
+      u[zs] = fsg_mix(b.w_lo, fsg_mix(a.w_lo, f00, a.w_hi, f10), b.w_hi, fsg_mix(a.w_lo, f01, a.w_hi, f11));
+    }
+  }
+}
+
+__device__ __forceinline__ void affine_clamp(const FsgDeformK& D, float px, float py, float pz, float& x, float& y,
+                                             float& z) {
+  x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
+  y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
+  z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  if (x < 0.f) x = 0.f;
+  if (y < 0.f) y = 0.f;
+  if (z < 0.f) z = 0.f;
+  if (x > hx) x = hx;
+  if (y > hy) y = hy;
+  if (z > hz) z = hz;
+}
+
+template <typename LD, bool HAS_LIN, bool HAS_NN, bool FAST>
+__global__ __launch_bounds__(256) void warp_brick_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+                                                         const float* __restrict__ src_lin,
+                                                         float* __restrict__ out_lin,
+                                                         const uint8_t* __restrict__ src_nn,
+                                                         LD* __restrict__ out_nn, EpiK E) {
+  __shared__ __attribute__((aligned(16))) BrickLds S;
+  const int t = threadIdx.x;
+  const int nbk = (D.n2 + BRK - 1) / BRK, nbj = (D.n1 + BRJ - 1) / BRJ;
+  int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int kb = tile % nbk;
+  tile /= nbk;
+  const int jb = tile % nbj, ib = tile / nbj;
+  const int i0 = ib * BRI, j0 = jb * BRJ, k0 = kb * BRK;
+  const int k4 = t & 3, jj = (t >> 2) & 7, ii = t >> 5;
+  const int i = min(i0 + ii, D.n0 - 1), j = min(j0 + jj, D.n1 - 1);
+  const bool live_ij = (i0 + ii < D.n0) && (j0 + jj < D.n1);
+  const Margins m = load_margins(mm6);
+
+  // ---- 0. tables and coarse nodes of this brick -------------------------------------------------
+  if (t < 32) {
+    const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
+    fsg_tap a = none, b = none;
+    if (t < 8) {
+      const int q = min(i0 + t, D.n0 - 1);
+      if (D.field) a = D.tx[q];
+      if (E.bias) b = E.bx[q];
+    } else if (t < 16) {
+      const int q = min(j0 + t - 8, D.n1 - 1);
+      if (D.field) a = D.ty[q];
+      if (E.bias) b = E.by[q];
+    } else {
+      const int q = min(k0 + t - 16, D.n2 - 1);
+      if (D.field) a = D.tz[q];
+      if (E.bias) b = E.bz[q];
+    }
+    S.tap[t] = a;
+    S.btap[t] = b;
+  }
+  if (t < 3) { S.bb[t] = 0x7FFFFFFF; S.bb[3 + t] = -1; }
+  __syncthreads();
+  // windows (tables are non-decreasing in the output index)
+  const int xw0 = S.tap[0].lo, yw0 = S.tap[8].lo, zw0 = S.tap[16].lo;
+  const int nxw = S.tap[7].hi - xw0 + 1, nyw = S.tap[15].hi - yw0 + 1, nzw = S.tap[31].hi - zw0 + 1;
+  const int bxw0 = S.btap[0].lo, byw0 = S.btap[8].lo, bzw0 = S.btap[16].lo;
+  const int nbxw = S.btap[7].hi - bxw0 + 1, nbyw = S.btap[15].hi - byw0 + 1, nbzw = S.btap[31].hi - bzw0 + 1;
+  const bool win_ok = (!D.field || (nxw <= BR_W && nyw <= BR_W && nzw <= BR_W)) &&
+                      (!E.bias || (nbxw <= BR_W && nbyw <= BR_W && nbzw <= BR_W));
+  if (win_ok) {
+    if (D.field) {
+      const int nn3 = nxw * nyw * nzw * 3;
+      if (t < nn3) {
+        const int c = t % 3;
+        int r = t / 3;
+        const int zz = r % nzw;
+        r /= nzw;
+        const int yy = r % nyw, xx = r / nyw;
+        S.nodes_f[t] = D.field[(((size_t)(xw0 + xx) * D.f1 + (yw0 + yy)) * D.f2 + (zw0 + zz)) * 3 + c];
+      }
+    }
+    if (E.bias) {
+      const int nb3 = nbxw * nbyw * nbzw;
+      if (t >= 192 && t - 192 < nb3) {
+        int r = t - 192;
+        const int zz = r % nbzw;
+        r /= nbzw;
+        const int yy = r % nbyw, xx = r / nbyw;
+        S.nodes_b[t - 192] = E.bias[((size_t)(bxw0 + xx) * E.b1 + (byw0 + yy)) * E.b2 + (bzw0 + zz)];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 1. positions of this thread's 4 voxels ------------------------------------------------------
+  float x[4], y[4], z[4], bval[4];
+  {
+    float ux[BR_W], uy[BR_W], uz[BR_W], ub[BR_W];
+    const fsg_tap a = S.tap[ii], b = S.tap[8 + jj];
+    if (D.field && win_ok) {
+      window_xy<3>(S.nodes_f, nyw, nzw, 0, a, a.lo - xw0, a.hi - xw0, b, b.lo - yw0, b.hi - yw0, ux);
+      window_xy<3>(S.nodes_f, nyw, nzw, 1, a, a.lo - xw0, a.hi - xw0, b, b.lo - yw0, b.hi - yw0, uy);
+      window_xy<3>(S.nodes_f, nyw, nzw, 2, a, a.lo - xw0, a.hi - xw0, b, b.lo - yw0, b.hi - yw0, uz);
+    }
+    if (E.bias && win_ok) {
+      const fsg_tap ab = S.btap[ii], bb = S.btap[8 + jj];
+      window_xy<1>(S.nodes_b, nbyw, nbzw, 0, ab, ab.lo - bxw0, ab.hi - bxw0, bb, bb.lo - byw0, bb.hi - byw0, ub);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kq = 4 * k4 + q;
+      const int k = min(k0 + kq, D.n2 - 1);
+      bval[q] = 0.f;
+      if (win_ok) {
+        float px = (float)i - D.cen[0], py = (float)j - D.cen[1], pz = (float)k - D.cen[2];
+        if (D.field) {
+          const fsg_tap c = S.tap[16 + kq];
+          const int cl = c.lo - zw0, ch = c.hi - zw0;
+          px = px + fsg_mix(c.w_lo, sel4(ux, cl), c.w_hi, sel4(ux, ch));
+          py = py + fsg_mix(c.w_lo, sel4(uy, cl), c.w_hi, sel4(uy, ch));
+          pz = pz + fsg_mix(c.w_lo, sel4(uz, cl), c.w_hi, sel4(uz, ch));
+        }
+        affine_clamp(D, px, py, pz, x[q], y[q], z[q]);
+        if (E.bias) {
+          const fsg_tap cb = S.btap[16 + kq];
+          bval[q] = fsg_mix(cb.w_lo, sel4(ub, cb.lo - bzw0), cb.w_hi, sel4(ub, cb.hi - bzw0));
+        }
+      } else {
+        fsg_position(D, i, j, k, x[q], y[q], z[q]);
+        if (E.bias) bval[q] = fsg_tab_interp<1>(E.bias, E.b1, E.b2, 0, E.bx[i], E.by[j], E.bz[k]);
+      }
+      x[q] = x[q] - m.mx;
+      y[q] = y[q] - m.my;
+      z[q] = z[q] - m.mz;
+    }
+  }
+
+  // ---- 1b. bounding box of all neighbourhoods --------------------------------------------------------
+  int lo0 = 0x7FFFFFFF, lo1 = 0x7FFFFFFF, lo2 = 0x7FFFFFFF, hi0 = -1, hi1 = -1, hi2 = -1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a0 = min(max((int)floorf(x[q]), 0), D.n0 - 1), a1 = min(max((int)floorf(y[q]), 0), D.n1 - 1),
+              a2 = min(max((int)floorf(z[q]), 0), D.n2 - 1);
+    lo0 = min(lo0, a0); hi0 = max(hi0, min(a0 + 1, D.n0 - 1));
+    lo1 = min(lo1, a1); hi1 = max(hi1, min(a1 + 1, D.n1 - 1));
+    lo2 = min(lo2, a2); hi2 = max(hi2, min(a2 + 1, D.n2 - 1));
+  }
+  lo0 = wave_min_i(lo0); lo1 = wave_min_i(lo1); lo2 = wave_min_i(lo2);
+  hi0 = wave_max_i(hi0); hi1 = wave_max_i(hi1); hi2 = wave_max_i(hi2);
+  if ((t & 63) == 0) {
+    atomicMin(&S.bb[0], lo0); atomicMin(&S.bb[1], lo1); atomicMin(&S.bb[2], lo2);
+    atomicMax(&S.bb[3], hi0); atomicMax(&S.bb[4], hi1); atomicMax(&S.bb[5], hi2);
+  }
+  __syncthreads();
+  const int X0 = S.bb[0], Y0 = S.bb[1], Z0 = S.bb[2] & ~3;  // z start aligned to 16 bytes
+  const int ex = S.bb[3] - X0 + 1, ey = S.bb[4] - Y0 + 1;
+  const int ez4 = ((S.bb[5] - Z0) >> 2) + 1;                // 16-byte chunks per row
+  const int pitch = ez4 * 4;
+  const int nchunk = ex * ey * ez4;
+  const bool fits = nchunk * 4 <= BR_CAP;
+
+  // ---- 2. copy the box to LDS ----------------------------------------------------------------------------
+  if (fits) {
+    const float inv_e = 1.0f / (float)ez4, inv_y = 1.0f / (float)ey;
+    for (int c = t; c < nchunk; c += 256) {
+      int r = (int)((float)c * inv_e);
+      if (r * ez4 > c) --r; else if ((r + 1) * ez4 <= c) ++r;
+      const int q = c - r * ez4;
+      int rx = (int)((float)r * inv_y);
+      if (rx * ey > r) --rx; else if ((rx + 1) * ey <= r) ++rx;
+      const int ry = r - rx * ey;
+      int xs = X0 + rx;
+      if (D.flip) xs = D.n0 - 1 - xs;
+      const size_t g = ((size_t)xs * D.n1 + (Y0 + ry)) * D.n2 + Z0 + 4 * q;
+      if (HAS_LIN) reinterpret_cast<float4*>(S.box)[c] = *reinterpret_cast<const float4*>(src_lin + g);
+      if (HAS_NN) S.lab[c] = *reinterpret_cast<const uint32_t*>(src_nn + g);
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. gather, blend, epilogue, store ------------------------------------------------------------------
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  float v[4];
+  uint32_t lab4 = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (HAS_NN) {
+      int xi = (int)rintf(x[q]), yi = (int)rintf(y[q]), zi = (int)rintf(z[q]);
+      xi = min(max(xi, 0), D.n0 - 1);
+      yi = min(max(yi, 0), D.n1 - 1);
+      zi = min(max(zi, 0), D.n2 - 1);
+      uint32_t l;
+      if (fits) {
+        const int idx = ((xi - X0) * ey + (yi - Y0)) * pitch + (zi - Z0);
+        l = (S.lab[idx >> 2] >> (8 * (idx & 3))) & 255u;
+      } else {
+        const int xs = D.flip ? D.n0 - 1 - xi : xi;
+        l = src_nn[((size_t)xs * D.n1 + yi) * D.n2 + zi];
+      }
+      lab4 |= l << (8 * q);
+    }
+    if (HAS_LIN) {
+      const bool ok = (x[q] > 0.f) && (y[q] > 0.f) && (z[q] > 0.f) && (x[q] <= hx) && (y[q] <= hy) && (z[q] <= hz);
+      float r = 0.f;
+      if (ok) {
+        const float fx = floorf(x[q]), fy = floorf(y[q]), fz = floorf(z[q]);
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+        const int dx = min(x0 + 1, D.n0 - 1) - x0, dy = min(y0 + 1, D.n1 - 1) - y0, dz = min(z0 + 1, D.n2 - 1) - z0;
+        const float bx = x[q] - fx, by = y[q] - fy, bz = z[q] - fz;
+        const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
+        float c000, c100, c010, c110, c001, c101, c011, c111;
+        if (fits) {
+          const int b00 = ((x0 - X0) * ey + (y0 - Y0)) * pitch + (z0 - Z0);
+          const int sxl = dx * ey * pitch, syl = dy * pitch;
+          c000 = S.box[b00];             c001 = S.box[b00 + dz];
+          c100 = S.box[b00 + sxl];       c101 = S.box[b00 + sxl + dz];
+          c010 = S.box[b00 + syl];       c011 = S.box[b00 + syl + dz];
+          c110 = S.box[b00 + sxl + syl]; c111 = S.box[b00 + sxl + syl + dz];
+        } else {
+          int xs0 = x0, xs1 = x0 + dx;
+          if (D.flip) { xs0 = D.n0 - 1 - xs0; xs1 = D.n0 - 1 - xs1; }
+          const float* r00 = src_lin + ((size_t)xs0 * D.n1 + y0) * D.n2 + z0;
+          const float* r10 = src_lin + ((size_t)xs1 * D.n1 + y0) * D.n2 + z0;
+          const float* r01 = src_lin + ((size_t)xs0 * D.n1 + y0 + dy) * D.n2 + z0;
+          const float* r11 = src_lin + ((size_t)xs1 * D.n1 + y0 + dy) * D.n2 + z0;
+          c000 = r00[0]; c001 = r00[dz]; c100 = r10[0]; c101 = r10[dz];
+          c010 = r01[0]; c011 = r01[dz]; c110 = r11[0]; c111 = r11[dz];
+        }
+        const float c00 = c000 * ax + c100 * bx;
+        const float c01 = c001 * ax + c101 * bx;
+        const float c10 = c010 * ax + c110 * bx;
+        const float c11 = c011 * ax + c111 * bx;
+        const float c0 = c00 * ay + c10 * by;
+        const float c1 = c01 * ay + c11 * by;
+        r = c0 * az + c1 * bz;
+      }
+      if (E.gamma > 0.f) {
+        if (FAST) r = 300.0f * __builtin_amdgcn_exp2f(E.gamma * (__builtin_amdgcn_logf(r) - 8.2288186904958804f));
+        else r = 300.0f * powf(r / 300.0f, E.gamma);
+      }
+      if (E.bias) r = r * (FAST ? __builtin_amdgcn_exp2f(bval[q] * 1.4426950408889634f) : expf(bval[q]));
+      v[q] = r;
+    }
+  }
+  const int k = k0 + 4 * k4;
+  if (live_ij && k < D.n2) {  // n2 % 4 == 0: the four voxels are all inside or all outside
+    const size_t o = ((size_t)i * D.n1 + j) * D.n2 + k;
+    if (HAS_LIN) *reinterpret_cast<float4*>(out_lin + o) = make_float4(v[0], v[1], v[2], v[3]);
+    if (HAS_NN) {
+      if (sizeof(LD) == 1) {
+        *reinterpret_cast<uint32_t*>(out_nn + o) = lab4;
+      } else {
+        *reinterpret_cast<float4*>(out_nn + o) = make_float4((float)(lab4 & 255u), (float)((lab4 >> 8) & 255u),
+                                                             (float)((lab4 >> 16) & 255u), (float)(lab4 >> 24));
+      }
+    }
+  }
+}
+
 int fill_epilogue(const fsg_epilogue* e, EpiK& K) {
   K.gamma = 0.f; K.bias = nullptr; K.bx = K.by = K.bz = nullptr; K.b0 = K.b1 = K.b2 = 0;
   if (!e) return 0;
@@ -636,10 +1027,29 @@ int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, f
   if (rc) return rc;
   const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
   if (D.rows && D.row_stride < need) return FSG_E_BADARG;
-  if (need <= ROWCAP && D.n2 >= 2 && !(g_tuning_flags & FSG_TUNE_GENERIC_WARP)) {
-    const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
+  if (need <= PATCH_ROWCAP && D.n2 >= 2 && !(g_tuning_flags & (FSG_TUNE_GENERIC_WARP | FSG_TUNE_NO_PATCH))) {
+    const int ntiles = ((D.n0 + PATCH - 1) / PATCH) * ((D.n1 + PATCH - 1) / PATCH);
     const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
-    const dim3 grid((unsigned)(D.n0 * tiles_j)), block(256);
+    const dim3 grid((unsigned)ntiles), block(1024);
+    hipStream_t st = fsg_stream(stream);
+#define FSG_LAUNCH_PATCH(L, N, F) \
+  hipLaunchKernelGGL((warp_patch_kernel<LT, L, N, F>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+    if (src_lin && src_nn) { if (fast) FSG_LAUNCH_PATCH(true, true, true); else FSG_LAUNCH_PATCH(true, true, false); }
+    else if (src_lin)      { if (fast) FSG_LAUNCH_PATCH(true, false, true); else FSG_LAUNCH_PATCH(true, false, false); }
+    else                   { FSG_LAUNCH_PATCH(false, true, true); }
+#undef FSG_LAUNCH_PATCH
+    FSG_RETURN_LAUNCH();
+  }
+  if (need <= ROWCAP && D.n2 >= 2 && !(g_tuning_flags & FSG_TUNE_GENERIC_WARP)) {
+#if FSG_WARP_MAP == 2
+    const int tiles_j = (D.n1 + 2 * WARP_ROWS_PER_WAVE - 1) / (2 * WARP_ROWS_PER_WAVE);
+    const int ntiles = ((D.n0 + 1) / 2) * tiles_j;
+#else
+    const int tiles_j = (D.n1 + 4 * WARP_ROWS_PER_WAVE - 1) / (4 * WARP_ROWS_PER_WAVE);
+    const int ntiles = D.n0 * tiles_j;
+#endif
+    const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
+    const dim3 grid((unsigned)ntiles), block(256);
     hipStream_t st = fsg_stream(stream);
 #define FSG_LAUNCH_WARP(L, N, F) \
   hipLaunchKernelGGL((warp_rows_kernel<LT, L, N, F>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
@@ -651,6 +1061,37 @@ int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, f
   }
   hipLaunchKernelGGL(warp_kernel<LT>, fsg_grid3(D.n0, D.n1, D.n2), fsg_block3(), 0, fsg_stream(stream), D, mm6,
                      src_lin, out_lin, src_nn, out_nn, E);
+  FSG_RETURN_LAUNCH();
+}
+
+
+// nearest-neighbour source as uint8 (label volumes), output uint8 or float32
+template <typename LD>
+int launch_warp_u8src(const fsg_deform* d, const int32_t* mm6, const float* src_lin, float* out_lin,
+                      const uint8_t* src_nn, LD* out_nn, const fsg_epilogue* epi, void* stream) {
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  if (!mm6) return FSG_E_BADARG;
+  if ((src_lin == nullptr) != (out_lin == nullptr)) return FSG_E_BADARG;
+  if ((src_nn == nullptr) != (out_nn == nullptr)) return FSG_E_BADARG;
+  if (!src_lin && !src_nn) return FSG_E_BADARG;
+  EpiK E;
+  rc = fill_epilogue(epi, E);
+  if (rc) return rc;
+  const uintptr_t al16 = (uintptr_t)src_lin | (uintptr_t)out_lin | (sizeof(LD) == 4 ? (uintptr_t)out_nn : 0);
+  const uintptr_t al4 = (uintptr_t)src_nn | (sizeof(LD) == 1 ? (uintptr_t)out_nn : 0);
+  if ((D.n2 & 3) || (al16 & 15) || (al4 & 3) || D.n2 < 4 || !(g_tuning_flags & FSG_TUNE_BRICK)) return FSG_E_ALIGN;
+  const int nb = ((D.n0 + BRI - 1) / BRI) * ((D.n1 + BRJ - 1) / BRJ) * ((D.n2 + BRK - 1) / BRK);
+  const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
+  const dim3 grid((unsigned)nb), block(256);
+  hipStream_t st = fsg_stream(stream);
+#define FSG_LAUNCH_BRICK(L, N, F) \
+  hipLaunchKernelGGL((warp_brick_kernel<LD, L, N, F>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+  if (src_lin && src_nn) { if (fast) FSG_LAUNCH_BRICK(true, true, true); else FSG_LAUNCH_BRICK(true, true, false); }
+  else if (src_lin)      { if (fast) FSG_LAUNCH_BRICK(true, false, true); else FSG_LAUNCH_BRICK(true, false, false); }
+  else                   { FSG_LAUNCH_BRICK(false, true, true); }
+#undef FSG_LAUNCH_BRICK
   FSG_RETURN_LAUNCH();
 }
 
@@ -769,7 +1210,14 @@ int fsg_warp_f32(const fsg_deform* d, const int32_t* mm6, const float* src_lin, 
 
 int fsg_warp_f32_u8(const fsg_deform* d, const int32_t* mm6, const float* src_lin, float* out_lin,
                     const uint8_t* src_nn, uint8_t* out_nn, const fsg_epilogue* epi, void* stream) {
+  const int rc = launch_warp_u8src<uint8_t>(d, mm6, src_lin, out_lin, src_nn, out_nn, epi, stream);
+  if (rc != FSG_E_ALIGN) return rc;  // brick kernel not selected / not applicable: patch or row kernel
   return launch_warp<uint8_t>(d, mm6, src_lin, out_lin, src_nn, out_nn, epi, stream);
+}
+
+int fsg_warp_f32_u8_to_f32(const fsg_deform* d, const int32_t* mm6, const float* src_lin, float* out_lin,
+                           const uint8_t* src_nn, float* out_nn, const fsg_epilogue* epi, void* stream) {
+  return launch_warp_u8src<float>(d, mm6, src_lin, out_lin, src_nn, out_nn, epi, stream);
 }
 
 int fsg_interp3d_f32(const float* src, int sx, int sy, int sz, const float* ii, const float* jj, const float* kk,

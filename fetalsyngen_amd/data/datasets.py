@@ -157,8 +157,16 @@ class FetalSynthDataset(FetalDataset):
         if not self.cache_on_device:
             return self.loader(self.segm_paths[idx])
         if idx not in self._segs:
-            self._segs[idx] = self.loader(self.segm_paths[idx]).float().to(self.generator.device)
-        return self._segs[idx]
+            host = self.loader(self.segm_paths[idx]).float()
+            dev = host.to(self.generator.device)
+            # uint8 twin for the label gather when the segmentation is integer valued in 0..255 (always the
+            # case for dseg files); results are identical, the kernel reads 1 byte instead of 4 per voxel
+            ok = bool(torch.equal(host, host.round()) and host.min() >= 0 and host.max() <= 255)
+            self._segs[idx] = (dev, dev.to(torch.uint8) if ok else None)
+        return self._segs[idx][0]
+
+    def _segmentation_u8(self, idx):
+        return self._segs[idx][1] if (self.cache_on_device and idx in self._segs) else None
 
     def sample(self, idx, genparams: dict = {}):
         image = self.loader(self.img_paths[idx]).float() if self.load_image else None
@@ -177,7 +185,8 @@ class FetalSynthDataset(FetalDataset):
         }
         t0 = time.time()
         gen_output, segmentation, image, synth_params = self.generator._pipeline(
-            image, segm, seeds, genparams, scale01=True)
+            image, segm, seeds, genparams, scale01=True,
+            segmentation_u8=self._segmentation_u8(idx) if self.return_device else None)
         if image is not None:
             from .. import kernels as K
 

@@ -137,19 +137,21 @@ class SpatialDeformation:
         return image, segmentation, output
 
     def run(self, plan: DeformPlan, image, segmentation, output, spec=None, mm6=None, gamma=None, bias=None,
-            bias_tabs=None):
+            bias_tabs=None, segmentation_u8=None):
         """Fused execution: one min/max launch + one warp launch (+ one more if `image` is given)."""
         if not plan.active:
             return image, segmentation, output
         if spec is None:
             spec = self.make_spec(plan, output.shape, flip_in_kernel=True).build()
-        if not spec.c.rows:
-            spec.prepare_rows(bias, bias_tabs)
         if mm6 is None:
             mm6 = K.coords_floormin(spec)
         seg = segmentation.to(self.device).contiguous()
         if seg.dtype not in (torch.float32, torch.uint8):
             seg = seg.float()
+        if segmentation_u8 is not None and tuple(segmentation_u8.shape) == tuple(seg.shape):
+            seg = segmentation_u8.contiguous()  # caller asked for uint8 labels in and out (1 B/voxel each way)
+        if not spec.c.rows:
+            spec.prepare_rows(bias, bias_tabs)
         out, seg = K.warp(spec, mm6, src_lin=output.contiguous(), src_nn=seg, gamma=gamma, bias=bias,
                           bias_tabs=bias_tabs)
         if image is not None:

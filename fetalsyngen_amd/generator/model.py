@@ -158,7 +158,7 @@ class FetalSynthGen:
         out, seg, img, params = self._pipeline(image, segmentation, seeds, genparams, scale01=False)
         return out, seg, img, params
 
-    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool):
+    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
         if genparams:
             genparams = self._validated_genparams(genparams)
         dev = self.device
@@ -234,10 +234,9 @@ class FetalSynthGen:
             mm8 = K.new_minmax(dev, 4, 4)
             if dplan.active:
                 spec = sb.build()
-                spec.prepare_rows(bias_dev, bias_tabs)
                 image, segmentation, output = sd.run(dplan, image, segmentation, output, spec=spec,
                                                      mm6=K.coords_floormin(spec, mm8), gamma=gam, bias=bias_dev,
-                                                     bias_tabs=bias_tabs)
+                                                     bias_tabs=bias_tabs, segmentation_u8=segmentation_u8)
             else:
                 segmentation = segmentation.to(dev)
                 if gam is not None:

@@ -328,26 +328,40 @@ def coords(spec: DeformSpec, mm6):
     return out
 
 
-def warp(spec: DeformSpec, mm6, src_lin=None, src_nn=None, gamma=None, bias=None, bias_tabs=None):
-    """Fused warp: returns (out_lin | None, out_nn | None)."""
+def warp(spec: DeformSpec, mm6, src_lin=None, src_nn=None, gamma=None, bias=None, bias_tabs=None, nn_out=None):
+    """Fused warp: returns (out_lin | None, out_nn | None).
+
+    `src_nn` float32 -> float32 labels (reference contract); uint8 -> uint8, or float32 when
+    `nn_out=torch.float32` (uint8 device copy of a float32 segmentation, exact for 0..255)."""
     _need_gpu(mm6, src_lin, src_nn, bias)
-    for s in (src_lin, src_nn):
-        if s is not None and tuple(s.shape) != spec.shape:
-            raise ValueError(f"volume shape {tuple(s.shape)} != grid {spec.shape}")
+    for s_ in (src_lin, src_nn):
+        if s_ is not None and tuple(s_.shape) != spec.shape:
+            raise ValueError(f"volume shape {tuple(s_.shape)} != grid {spec.shape}")
     out_lin = torch.empty_like(_f32(src_lin)) if src_lin is not None else None
-    out_nn = torch.empty_like(src_nn) if src_nn is not None else None
     epi = _epilogue(gamma, bias, bias_tabs, spec.shape)
     if spec.c.rows and (int(bias.shape[2]) if bias is not None else 0) > getattr(spec, "_rows_bias", 0):
         raise ValueError("row workspace was prepared without this bias grid; call prepare_rows(bias, bias_tabs)")
     lib = _lib.load()
+    args = lambda src, out: (C.byref(spec.c), _p(mm6), _p(src_lin), _p(out_lin), _p(src), _p(out), C.byref(epi),
+                             _stream(mm6))
     if src_nn is None or src_nn.dtype == F32:
-        fn, name = lib.fsg_warp_f32, "fsg_warp_f32"
+        out_nn = torch.empty_like(src_nn) if src_nn is not None else None
+        _lib.check(lib.fsg_warp_f32(*args(src_nn, out_nn)), "fsg_warp_f32")
     elif src_nn.dtype == torch.uint8:
-        fn, name = lib.fsg_warp_f32_u8, "fsg_warp_f32_u8"
+        if nn_out in (None, torch.uint8):
+            out_nn = torch.empty_like(src_nn)
+            _lib.check(lib.fsg_warp_f32_u8(*args(src_nn, out_nn)), "fsg_warp_f32_u8")
+        elif nn_out == F32:
+            out_nn = torch.empty(src_nn.shape, dtype=F32, device=src_nn.device)
+            rc = lib.fsg_warp_f32_u8_to_f32(*args(src_nn, out_nn))
+            if rc == _lib.E_ALIGN:  # outside the brick kernel's domain: float32 label volume, row kernel
+                _lib.check(lib.fsg_warp_f32(*args(src_nn.to(F32), out_nn)), "fsg_warp_f32")
+            else:
+                _lib.check(rc, "fsg_warp_f32_u8_to_f32")
+        else:
+            raise TypeError("nn_out must be torch.uint8 or torch.float32")
     else:
         raise TypeError("nearest-neighbour volume must be float32 or uint8")
-    _lib.check(fn(C.byref(spec.c), _p(mm6), _p(src_lin), _p(out_lin), _p(src_nn), _p(out_nn), C.byref(epi), _stream(mm6)),
-               name)
     return out_lin, out_nn
 
 

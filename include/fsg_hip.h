@@ -71,6 +71,8 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_PRECISE_MATH 2  /* OCML powf/expf in the gamma/bias epilogue instead of v_log/v_exp */
 #define FSG_TUNE_GENERIC_ZOOM 4  /* per-voxel 8-tap zoom instead of the row-wise LDS kernels */
 #define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
+#define FSG_TUNE_NO_PATCH 32     /* row kernel (4 waves, own rows) instead of the 16-wave lockstep patch kernel */
+#define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
 
 /* ---- RNG ------------------------------------------------------------------------------------ */
@@ -165,6 +167,13 @@ int fsg_warp_f32(const fsg_deform* d_host, const int32_t* mm6, const float* src_
 /* Same with uint8 label volumes for the nearest leg (device-resident streaming path). */
 int fsg_warp_f32_u8(const fsg_deform* d_host, const int32_t* mm6, const float* src_lin, float* out_lin,
                     const uint8_t* src_nn, uint8_t* out_nn, const fsg_epilogue* epi_host, void* stream);
+
+/* Label volume read as uint8, deformed labels written as float32 (exact for 0..255): the reference keeps
+ * segmentations as float32 tensors, the device-resident copy is uint8.  Served by the LDS brick kernel only
+ * (FSG_TUNE_BRICK set, shape[2] % 4 == 0, 16-byte aligned fp32 volumes); returns FSG_E_ALIGN otherwise and
+ * the caller uses fsg_warp_f32 / fsg_warp_f32_u8. */
+int fsg_warp_f32_u8_to_f32(const fsg_deform* d_host, const int32_t* mm6, const float* src_lin, float* out_lin,
+                           const uint8_t* src_nn, float* out_nn, const fsg_epilogue* epi_host, void* stream);
 
 /* Generic gather with explicit coordinate volumes (utils/generation.py:204-288 fast_3D_interp_torch).
  * mode 0 = linear (default_value outside), 1 = nearest.  src (sx,sy,sz); npts coordinates. */

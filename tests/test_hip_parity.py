@@ -523,3 +523,61 @@ def test_gmm_from_label_parts_equals_gmm_of_the_sum(K):
         assert torch.equal(bank.combined(m2s), comb)
         z = torch.randn(shape).to(DEV)
         assert torch.equal(K.gmm_sample_parts(bank.parts(m2s), mus, sig, noise=z), K.gmm_sample(comb, mus, sig, noise=z))
+
+
+@pytest.mark.parametrize("case", ["typical", "extreme", "fine_grid", "no_field"])
+def test_brick_kernel_equals_row_kernel(K, case):
+    """LDS-brick warp (uint8 labels) vs the row kernel: bit-identical image and labels, with/without flip,
+    ragged brick counts, boxes that do not fit LDS (extreme) and coarse windows wider than 4 nodes."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import tables as T
+    from fetalsyngen_amd.utils.generation import make_affine_matrix
+
+    lib = _lib.load()
+    rs = np.random.RandomState(11)
+    shape = {"typical": (70, 60, 100), "extreme": (64, 64, 64), "fine_grid": (40, 40, 40), "no_field": (33, 17, 48)}[case]
+    rot = {"typical": 0.15, "extreme": 0.7, "fine_grid": 0.1, "no_field": 0.2}[case]
+    fsh = {"typical": (5, 4, 7), "extreme": (4, 4, 4), "fine_grid": (20, 20, 20), "no_field": None}[case]
+    A = make_affine_matrix([rot, -rot, rot], [0.01, -0.02, 0.015], [1.05, 0.95, 1.02]).astype(np.float32)
+    c = (np.array(shape) - 1) / 2
+    img = (rs.rand(*shape) * 255).astype(np.float32)
+    lab = rs.randint(0, 8, shape).astype(np.uint8)
+    bias = (rs.randn(3, 2, 4) * 0.3).astype(np.float32)
+    bt = K.DeviceTables(T.zoom_tables(bias.shape, np.array(shape) / np.array(bias.shape))[0], DEV)
+    for flip in (False, True):
+        fs, ft = None, None
+        if fsh is not None:
+            fs = dev((rs.randn(*fsh, 3) * (6.0 if case == "extreme" else 2.0)).astype(np.float32))
+            ft = K.DeviceTables(T.zoom_tables(fsh, np.array(shape) / np.array(fsh))[0], DEV)
+        spec = K.DeformSpec(shape, A, c, c.astype(np.float32) + np.float32(0.3), flip, fs, ft, device=DEV)
+        mm = K.coords_floormin(spec)
+        outs = {}
+        for flags in (16, 0):
+            prev = lib.fsg_set_tuning(flags)
+            try:
+                a, l8 = K.warp(spec, mm, src_lin=dev(img), src_nn=dev(lab), gamma=0.9, bias=dev(bias), bias_tabs=bt)
+                b, lf = K.warp(spec, mm, src_lin=dev(img), src_nn=dev(lab), nn_out=torch.float32)
+                _, l8o = K.warp(spec, mm, src_nn=dev(lab))
+                p, _ = K.warp(spec, mm, src_lin=dev(img))
+                outs[flags] = [host(v) for v in (a, l8, b, lf, l8o, p)]
+            finally:
+                lib.fsg_set_tuning(prev)
+        for u, v in zip(outs[16], outs[0]):  # brick kernel (16) vs default kernels
+            assert np.array_equal(u, v), (case, flip)
+        assert np.array_equal(outs[0][1], outs[0][3].astype(np.uint8)) and np.array_equal(outs[0][1], outs[0][4])
+        # and against the float32-label kernels: 16-wave patch kernel (default), row kernel (flag 32), and with
+        # the precomputed row workspace
+        f32 = {}
+        for flags in (0, 32):
+            prev = lib.fsg_set_tuning(flags)
+            try:
+                a, lf32 = K.warp(spec, mm, src_lin=dev(img), src_nn=dev(lab.astype(np.float32)), gamma=0.9,
+                                 bias=dev(bias), bias_tabs=bt)
+                f32[flags] = (host(a), host(lf32))
+            finally:
+                lib.fsg_set_tuning(prev)
+        spec.prepare_rows(dev(bias), bt)
+        a, lf32 = K.warp(spec, mm, src_lin=dev(img), src_nn=dev(lab.astype(np.float32)), gamma=0.9, bias=dev(bias),
+                         bias_tabs=bt)
+        for got in (f32[0], f32[32], (host(a), host(lf32))):
+            assert np.array_equal(got[0], outs[0][0]) and np.array_equal(got[1], outs[0][3]), (case, flip)
