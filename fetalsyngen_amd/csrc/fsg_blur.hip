@@ -40,13 +40,16 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const float* __restri
 }
 
 // ---- strided axes, float4 lanes, register window ----------------------------------------------
-// grid: x = inner/4 chunks of 64 lanes, y = ceil(len / TL), z = outer
+// Volume viewed as (outer, len, inner4 float4 columns); blur along `len`.  A thread owns one float4 column
+// and TL consecutive outputs: TL + 2R coalesced row loads, TL stores, taps from the kernel arguments.
+// Block = 64 columns x 4 chunks (threadIdx.y), so that narrow slabs (axis 1: inner4 = nz/4 = 64) still
+// fill every lane; grid: x = column groups, y = groups of 4 chunks, z = outer.
 template <int R, int TL>
 __global__ __launch_bounds__(256) void blur_strided_v4(const float4* __restrict__ src, float4* __restrict__ dst,
                                                        int len, int inner4, Taps T) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // float4 column
-  if (c >= inner4) return;
-  const int l0 = blockIdx.y * TL;
+  const int c = blockIdx.x * 64 + threadIdx.x;  // float4 column
+  const int l0 = (blockIdx.y * 4 + threadIdx.y) * TL;
+  if (c >= inner4 || l0 >= len) return;
   const size_t slab = (size_t)blockIdx.z * len * inner4;
   const float4* s = src + slab + c;
   float4 acc[TL];
@@ -120,9 +123,13 @@ __global__ __launch_bounds__(256) void blur_contig_lds(const float* __restrict__
 
 template <int R>
 int launch_strided(const float* src, float* dst, int outer, int len, int inner, const Taps& T, hipStream_t st) {
-  constexpr int TL = 16;
+#ifndef FSG_BLUR_TL
+#define FSG_BLUR_TL 24  // measured on MI355X at 256^3: 24 beats 16 (fewer halo re-reads) and 32 (register pressure)
+#endif
+  constexpr int TL = FSG_BLUR_TL;
   const int inner4 = inner / 4;
-  dim3 block(256), grid((unsigned)((inner4 + 255) / 256), (unsigned)((len + TL - 1) / TL), (unsigned)outer);
+  const int chunks = (len + TL - 1) / TL;
+  dim3 block(64, 4), grid((unsigned)((inner4 + 63) / 64), (unsigned)((chunks + 3) / 4), (unsigned)outer);
   hipLaunchKernelGGL((blur_strided_v4<R, TL>), grid, block, 0, st, reinterpret_cast<const float4*>(src),
                      reinterpret_cast<float4*>(dst), len, inner4, T);
   FSG_RETURN_LAUNCH();

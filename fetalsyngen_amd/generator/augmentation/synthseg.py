@@ -110,7 +110,8 @@ class RandBiasField(RandTransform):
         size = np.maximum(np.round(scale * np.array(tuple(image_size))).astype(int), 1).tolist()
         std = genparams["bf_std"] if "bf_std" in genparams else (
             self.std_min + (self.std_max - self.std_min) * np.random.rand(1))
-        p.grid = torch.tensor(std, dtype=torch.float32) * torch.randn(size, dtype=torch.float32)
+        std32 = np.asarray(std, dtype=np.float32)  # same rounding as torch.tensor(std, dtype=float32)
+        p.grid = torch.from_numpy(std32 * torch.randn(size, dtype=torch.float32).numpy())
         p.params = {"bf_scale": scale, "bf_std": std, "bf_size": size}
         return p
 
@@ -153,7 +154,7 @@ class RandNoise(RandTransform):
         p.active = True
         std = genparams["noise_std"] if "noise_std" in genparams else (
             self.std_min + (self.std_max - self.std_min) * np.random.rand(1))
-        p.std32 = float(torch.tensor(std, dtype=torch.float32).reshape(-1)[0].item())
+        p.std32 = float(np.asarray(std, dtype=np.float32).reshape(-1)[0])  # == torch.tensor(std, f32).item()
         p.field = rng.normal_field(tuple(shape), stream_id=2)
         return p
 

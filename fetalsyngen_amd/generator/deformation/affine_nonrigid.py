@@ -73,14 +73,16 @@ class SpatialDeformation:
             (2 * self.max_rotation * np.random.rand(3) - self.max_rotation) / 180.0 * np.pi)
         shr = ga["shears"] if "shears" in ga else 2 * self.max_shear * np.random.rand(3) - self.max_shear
         scl = ga["scalings"] if "scalings" in ga else 1 + (2 * self.max_scaling * np.random.rand(3) - self.max_scaling)
-        p.A = torch.tensor(make_affine_matrix(rot, shr, scl), dtype=torch.float32)
-        centre = torch.tensor((shp - 1) / 2, dtype=torch.float32)
+        p.A = torch.from_numpy(make_affine_matrix(rot, shr, scl).astype(np.float32))
+        centre32 = ((shp - 1) / 2).astype(np.float32)
         if random_shift:
-            room = torch.tensor(shp - np.array(self.size), dtype=torch.float32) / 2
-            room = torch.clamp(room, min=0)
-            # float64 draw, always consumed; fp32 + fp64 promotes the centre to float64
-            centre = centre + (2 * (room * torch.rand(3, dtype=torch.float64)) - room)
-        p.c2 = centre
+            u = torch.rand(3, dtype=torch.float64).numpy()  # float64 draw, always consumed
+            room = np.maximum((shp - np.asarray(self.size)).astype(np.float32) / np.float32(2), np.float32(0))
+            # fp32 centre + fp64 shift promotes to float64 in the reference; with no room the shift is exactly 0
+            centre = centre32.astype(np.float64) + (2 * (room.astype(np.float64) * u) - room.astype(np.float64))
+        else:
+            centre = centre32
+        p.c2 = torch.from_numpy(np.ascontiguousarray(centre))
         aff_params = {"rotations": rot, "shears": shr, "scalings": scl}
 
         nr_params = {}

@@ -47,6 +47,7 @@ class ImageFromSeeds:
         self.generation_classes = generation_classes
         self.meta_labels = meta_labels
         self.loader = NiftiReader()
+        self._idx = None
 
     # -- seeds ------------------------------------------------------------------------------
     def draw_subclusters(self, genparams: dict = {}) -> dict:
@@ -75,20 +76,25 @@ class ImageFromSeeds:
 
     # -- intensities ------------------------------------------------------------------------
     def plan_intensities(self, shape, genparams: dict = {}) -> GMMPlan:
-        """torch draws in the reference's order: rand(nlabels), rand(nlabels), randn(nsamp), field."""
+        """torch draws in the reference's order: rand(nlabels), rand(nlabels), randn(nsamp), field.
+        The arithmetic on the 50-entry tables is done in numpy float32 (same IEEE operations as ATen,
+        a few times cheaper per call on arrays this small)."""
         nlabels = max(self.seed_labels) + 1
         if "mus" in genparams:
-            mus = torch.as_tensor(genparams["mus"]).detach().to("cpu", torch.float32).clone()
+            mus = torch.as_tensor(genparams["mus"]).detach().to("cpu", torch.float32).numpy().copy()
         else:
-            mus = 25 + 200 * torch.rand(nlabels, dtype=torch.float32)
+            mus = np.float32(25) + np.float32(200) * torch.rand(nlabels, dtype=torch.float32).numpy()
         if "sigmas" in genparams:
-            sigmas = torch.as_tensor(genparams["sigmas"]).detach().to("cpu", torch.float32).clone()
+            sigmas = torch.as_tensor(genparams["sigmas"]).detach().to("cpu", torch.float32).numpy().copy()
         else:
-            sigmas = 5 + 20 * torch.rand(nlabels, dtype=torch.float32)
+            sigmas = np.float32(5) + np.float32(20) * torch.rand(nlabels, dtype=torch.float32).numpy()
         if self.generation_classes != self.seed_labels:
-            tied = mus[self.generation_classes] + 25 * torch.randn(len(self.seed_labels), dtype=torch.float32)
-            mus[self.seed_labels] = torch.clamp(tied, 0, 225)
-        return GMMPlan(mus, sigmas, rng.normal_field(shape, stream_id=1))
+            if self._idx is None:
+                self._idx = (np.asarray(self.generation_classes), np.asarray(self.seed_labels))
+            z = torch.randn(len(self.seed_labels), dtype=torch.float32).numpy()
+            tied = mus[self._idx[0]] + np.float32(25) * z
+            mus[self._idx[1]] = np.minimum(np.maximum(tied, np.float32(0)), np.float32(225))
+        return GMMPlan(torch.from_numpy(mus), torch.from_numpy(sigmas), rng.normal_field(shape, stream_id=1))
 
     def run_intensities(self, seeds, device, plan: GMMPlan):
         if seeds.dtype not in (torch.uint8, torch.int64):

@@ -64,17 +64,21 @@ def position_table(pos64: np.ndarray, n_src: int) -> np.ndarray:
     return _pack(lo.numpy(), hi.numpy(), w_lo.numpy(), w_hi.numpy())
 
 
+_LOG5 = np.log(5)
+
+
 def resample_plan(in_shape, resolution, spacing, u_std: float):
     """Blur sigmas, low-res size, factors and per-axis tables of RandResample."""
-    spacing = np.array(spacing, dtype=np.float64)
-    resolution = np.array(resolution, dtype=np.float64)
-    size = np.array(in_shape)
-    stds = (0.85 + 0.3 * u_std) * np.log(5) / np.pi * spacing / resolution
+    spacing = np.asarray(spacing, dtype=np.float64)
+    resolution = np.asarray(resolution, dtype=np.float64)
+    size = np.asarray(in_shape)
+    stds = (0.85 + 0.3 * u_std) * _LOG5 / np.pi * spacing / resolution  # reference's association order
     stds[spacing <= resolution] = 0.0
     new_size = (size * resolution / spacing).astype(int)
     factors = new_size / size
-    tabs = [_resample_axis_table(int(new_size[a]), int(size[a])) for a in range(3)]
-    return stds, tuple(int(v) for v in new_size), factors, tabs
+    ns, sz = new_size.tolist(), size.tolist()
+    tabs = [_resample_axis_table(ns[a], sz[a]) for a in range(3)]
+    return stds, tuple(ns), factors, tabs
 
 
 @lru_cache(maxsize=1024)

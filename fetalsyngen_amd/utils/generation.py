@@ -20,32 +20,19 @@ from .. import kernels as K
 from .. import tables as T
 
 
-def _rot(axis: int, angle: float) -> np.ndarray:
-    c, s = np.cos(angle), np.sin(angle)
-    m = np.eye(3)
-    a, b = [(1, 2), (0, 2), (0, 1)][axis]
-    m[a, a] = c
-    m[b, b] = c
-    sign = -1.0 if axis != 1 else 1.0
-    m[a, b] = sign * s
-    m[b, a] = -sign * s
-    return m
-
-
-def _shear(col: int, sh) -> np.ndarray:
-    """Unit matrix with column `col` filled by the other rows' shear coefficients."""
-    m = np.eye(3)
-    for r in range(3):
-        if r != col:
-            m[r, col] = sh[r]
-    return m
-
-
 def make_affine_matrix(rot, sh, s) -> np.ndarray:
     """float64 3x3: shear(x) @ shear(y) @ shear(z) @ Rx @ Ry @ Rz, row r scaled by s[r]."""
-    A = _shear(0, sh) @ _shear(1, sh) @ _shear(2, sh) @ _rot(0, rot[0]) @ _rot(1, rot[1]) @ _rot(2, rot[2])
-    for r in range(3):
-        A[r, :] = A[r, :] * s[r]
+    c0, c1, c2 = np.cos(rot[0]), np.cos(rot[1]), np.cos(rot[2])
+    s0, s1, s2 = np.sin(rot[0]), np.sin(rot[1]), np.sin(rot[2])
+    h0, h1, h2 = sh[0], sh[1], sh[2]
+    shear_x = np.array([[1.0, 0.0, 0.0], [h1, 1.0, 0.0], [h2, 0.0, 1.0]])
+    shear_y = np.array([[1.0, h0, 0.0], [0.0, 1.0, 0.0], [0.0, h2, 1.0]])
+    shear_z = np.array([[1.0, 0.0, h0], [0.0, 1.0, h1], [0.0, 0.0, 1.0]])
+    rx = np.array([[1.0, 0.0, 0.0], [0.0, c0, -s0], [0.0, s0, c0]])
+    ry = np.array([[c1, 0.0, s1], [0.0, 1.0, 0.0], [-s1, 0.0, c1]])
+    rz = np.array([[c2, -s2, 0.0], [s2, c2, 0.0], [0.0, 0.0, 1.0]])
+    A = shear_x @ shear_y @ shear_z @ rx @ ry @ rz
+    A *= np.asarray(s, dtype=np.float64).reshape(3, 1)
     return A
 
 

@@ -309,7 +309,7 @@ class Config:
 
 
 def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_gmm=None, noise_lowres=None,
-               keep_stages=False):
+               keep_stages=False, image=None):
     """One `FetalSynthGen.sample` + the dataset's final [0,1] scaling, drawing from the
     numpy / torch GLOBAL generators in the reference's order
     (model.py:231-276 -> rand_gmm.py:82-85,:120-148 -> affine_nonrigid.py:140-145,:248-263,
@@ -323,29 +323,36 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     the torch generator exactly like the product's key draw does).
     Returns dict(out, seg, scaled, params, stages)."""
     st = {}
-    lo_s, hi_s = cfg.subclusters
-    m2s = {m: int(np.random.randint(lo_s, hi_s + 1)) for m in range(1, 5)}
-    seeds = None
-    for m in range(1, 5):
-        v = torch.as_tensor(np.asarray(seed_volumes[m2s[m]][m])).clone()
-        seeds = v if seeds is None else seeds + v
-    seeds = seeds.long()
+    if seed_volumes is not None:
+        lo_s, hi_s = cfg.subclusters
+        m2s = {m: int(np.random.randint(lo_s, hi_s + 1)) for m in range(1, 5)}
+        seeds = None
+        for m in range(1, 5):
+            v = torch.as_tensor(np.asarray(seed_volumes[m2s[m]][m])).clone()
+            seeds = v if seeds is None else seeds + v
+        seeds = seeds.long()
 
-    nlab = max(cfg.seed_labels) + 1
-    u_mu = torch.rand(nlab, dtype=F32)
-    u_sg = torch.rand(nlab, dtype=F32)
-    z_cls = None
-    if cfg.generation_classes != cfg.seed_labels:
-        z_cls = torch.randn(len(cfg.seed_labels), dtype=F32)
-    mus, sigmas = gmm_tables(u_mu, u_sg, z_cls, cfg.seed_labels, cfg.generation_classes)
-    if noise_gmm is None:
-        z = torch.randn(seeds.shape, dtype=F32)
+        nlab = max(cfg.seed_labels) + 1
+        u_mu = torch.rand(nlab, dtype=F32)
+        u_sg = torch.rand(nlab, dtype=F32)
+        z_cls = None
+        if cfg.generation_classes != cfg.seed_labels:
+            z_cls = torch.randn(len(cfg.seed_labels), dtype=F32)
+        mus, sigmas = gmm_tables(u_mu, u_sg, z_cls, cfg.seed_labels, cfg.generation_classes)
+        if noise_gmm is None:
+            z = torch.randn(seeds.shape, dtype=F32)
+        else:
+            z = noise_gmm(tuple(seeds.shape)) if callable(noise_gmm) else noise_gmm
+        out = gmm_image(seeds, mus, sigmas, z)
+        params = {"mlabel2subclusters": m2s, "mus": mus, "sigmas": sigmas}
     else:
-        z = noise_gmm(tuple(seeds.shape)) if callable(noise_gmm) else noise_gmm
-    out = gmm_image(seeds, mus, sigmas, z)
+        # image as intensity prior, scaled to 0..255 (generator/model.py:131-140)
+        if image is None:
+            raise ValueError("If no seeds are passed, an image must be loaded to be used as intensity prior!")
+        out = (image - image.min()) / (image.max() - image.min()) * 255
+        params = {}
     st["gmm"] = out
 
-    params = {"mlabel2subclusters": m2s, "mus": mus, "sigmas": sigmas}
     shape = tuple(out.shape)
     seg = segmentation
     coords, flip = None, False
@@ -373,6 +380,9 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     params["flip"] = flip
     out, seg = apply_deformation(out, seg, coords, flip)
     st["warped"] = out
+    image_def = None
+    if image is not None:  # the real image follows the same field, linear (affine_nonrigid.py:183,:190-191)
+        image_def, _ = apply_deformation(image, segmentation, coords, flip)
 
     gamma = None
     if np.random.rand() < cfg.gamma_prob:
@@ -413,4 +423,5 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     st["noisy"] = out
 
     out = resize_back(out, factors)
-    return {"out": out, "seg": seg, "scaled": scale01(out), "params": params, "stages": st if keep_stages else None}
+    return {"out": out, "seg": seg, "scaled": scale01(out), "params": params, "stages": st if keep_stages else None,
+            "image": image_def}

@@ -581,3 +581,95 @@ def test_brick_kernel_equals_row_kernel(K, case):
                          bias_tabs=bt)
         for got in (f32[0], f32[32], (host(a), host(lf32))):
             assert np.array_equal(got[0], outs[0][0]) and np.array_equal(got[1], outs[0][3]), (case, flip)
+
+
+# ---- the other entry modes of FetalSynthGen.sample ----------------------------------------------------
+def _phantom_image(shape):
+    g = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    return (100 * np.exp(-(g[0] ** 2 + 1.5 * g[1] ** 2 + 2 * g[2] ** 2)) + 20 * np.sin(5 * g[0] * g[1]) + 30).astype(np.float32)
+
+
+def test_image_is_deformed_with_the_same_field(K):
+    """load_image=True path (model.py:143-153): the real image is returned warped by the same field."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (40, 36, 28)
+    seg, seeds = make_seed_volumes(shape, 2)
+    img = _phantom_image(shape)
+    gen = make_generator(shape, DEV, rng="reference", nonlin_scale=(0.1, 0.2))
+    np.random.seed(21)
+    torch.manual_seed(21)
+    out, seg_d, img_d, params = gen.sample(image=t(img), segmentation=t(seg), seeds=seeds)
+    np.random.seed(21)
+    torch.manual_seed(21)
+    r = O.run_sample(O.Config(shape, prob=1.0, nonlin_scale=(0.1, 0.2)), t(seg), seeds, image=t(img))
+    assert np.array_equal(host(img_d), r["image"].numpy())
+    assert np.array_equal(host(seg_d), r["seg"].numpy())
+    np.testing.assert_allclose(host(out), r["out"].numpy(), rtol=RTOL, atol=2e-5)
+    # stage-wise API gives the same
+    np.random.seed(21)
+    torch.manual_seed(21)
+    o2, s2, i2, _ = gen.generate(image=t(img), segmentation=t(seg), seeds=seeds)
+    assert np.array_equal(host(i2), r["image"].numpy()) and np.array_equal(host(s2), r["seg"].numpy())
+
+
+def test_image_as_intensity_prior(K):
+    """seeds=None path (model.py:131-140): the image, scaled to 0..255, replaces the GMM draw."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (32, 32, 32)
+    seg, _ = make_seed_volumes(shape)
+    img = _phantom_image(shape)
+    gen = make_generator(shape, DEV, rng="reference", nonlin_scale=(0.1, 0.3))
+    for api in ("sample", "stagewise"):
+        np.random.seed(4)
+        torch.manual_seed(4)
+        if api == "sample":
+            out, seg_d, img_d, params = gen.sample(image=t(img), segmentation=t(seg), seeds=None)
+        else:
+            o, seg_d, img_d, p1 = gen.generate(image=t(img), segmentation=t(seg), seeds=None)
+            out, p2 = gen.augment(image=o, segmentation=seg_d)
+            params = {**p1, **p2}
+        assert params["selected_seeds"] == {} and params["seed_intensities"] == {}
+        np.random.seed(4)
+        torch.manual_seed(4)
+        r = O.run_sample(O.Config(shape, prob=1.0, nonlin_scale=(0.1, 0.3)), t(seg), None, image=t(img))
+        assert np.array_equal(host(seg_d), r["seg"].numpy())
+        np.testing.assert_allclose(host(out), r["out"].numpy(), rtol=RTOL, atol=2e-5)
+        np.testing.assert_allclose(host(img_d), r["image"].numpy(), rtol=0, atol=1e-4)
+
+
+def test_genparams_replay_fixes_the_augmentation_strengths(K):
+    """A returned `synth_params` dict passed back as `genparams` forces every gate and reproduces every
+    recorded parameter (docs/datasets.md of the reference: strengths are fixed, voxel noise is re-drawn)."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (32, 32, 32)
+    seg, seeds = make_seed_volumes(shape)
+    gen = make_generator(shape, DEV, rng="device", nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+    np.random.seed(8)
+    torch.manual_seed(8)
+    out1, seg1, _, p1 = gen.sample(image=None, segmentation=t(seg), seeds=seeds)
+    lazy = make_generator(shape, DEV, rng="device", prob=0.0, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+    np.random.seed(99)
+    torch.manual_seed(99)
+    out2, seg2, _, p2 = lazy.sample(image=None, segmentation=t(seg), seeds=seeds, genparams=p1)
+    assert p2["selected_seeds"] == p1["selected_seeds"]
+    # sigmas are taken as given; the class-tied means are re-perturbed on top of the given ones, exactly as
+    # the reference does (rand_gmm.py:139-145 runs even when "mus" is supplied); untied entries stay
+    assert torch.equal(p2["seed_intensities"]["sigmas"], p1["seed_intensities"]["sigmas"])
+    assert torch.equal(p2["seed_intensities"]["mus"][1:10], p1["seed_intensities"]["mus"][1:10])
+    for k in ("rotations", "shears", "scalings"):
+        assert np.array_equal(p2["deform_params"]["affine"][k], p1["deform_params"]["affine"][k])
+    assert p2["deform_params"]["flip"] == p1["deform_params"]["flip"]
+    assert p2["deform_params"]["non_rigid"]["size_F_small"] == p1["deform_params"]["non_rigid"]["size_F_small"]
+    assert p2["gamma_params"] == p1["gamma_params"] and p2["noise_params"] == p1["noise_params"]
+    assert p2["resample_params"] == p1["resample_params"] and p2["bf_params"]["bf_size"] == p1["bf_params"]["bf_size"]
+    assert out2.shape == out1.shape and not torch.equal(out2, out1)  # fields are re-drawn, as in the reference
+    # with no genparams and prob 0 nothing fires
+    np.random.seed(99)
+    torch.manual_seed(99)
+    out3, seg3, _, p3 = lazy.sample(image=None, segmentation=t(seg), seeds=seeds)
+    assert p3["deform_params"] == {"affine": None, "non_rigid": None, "flip": False}
+    assert p3["gamma_params"]["gamma"] is None and p3["resample_params"]["spacing"] is None
+    assert np.array_equal(host(seg3), seg)
