@@ -539,7 +539,7 @@ constexpr int PATCH = 4;
 constexpr int PATCH_ROWCAP = 128;
 
 template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
-__global__ __launch_bounds__(1024) void warp_patch_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+__global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
                                                           const float* __restrict__ src_lin,
                                                           float* __restrict__ out_lin,
                                                           const LT* __restrict__ src_nn, LT* __restrict__ out_nn,

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void zoom1_rows_kernel(ZoomK Z, EpiZ E, int ro
 // and the four source rows of row t+1 are in flight in registers while row t is blended and emitted, so
 // the dependent chain "table entry -> source rows -> LDS -> output" is paid once per wave, not per row.
 template <int EPI>
-__global__ __launch_bounds__(256) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, int rows_per_block) {
+__global__ __launch_bounds__(256, 8) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, int rows_per_block) {
   __shared__ float sm_all[4][2][256];
   __shared__ float red[2][4];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
