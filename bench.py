@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -45,6 +46,16 @@ def build_generator(shape, device, rng_mode):
         spatial_deform=SpatialDeformation(20, 0.02, 0.1, list(shape), p, True, 0.03, 0.06, 4, 0.5, device),
         resampler=RandResample(p, 0.5, 1.5), bias_field=RandBiasField(p, 0.004, 0.02, 0.01, 0.3),
         noise=RandNoise(p, 5, 15), gamma=RandGamma(p, 0.1), rng=rng_mode)
+
+
+def _drop_events(events):
+    from fetalsyngen_amd import _lib
+
+    lib = _lib.load()
+    for e0, e1, _ in events:
+        lib.fsg_event_destroy(e0)
+        lib.fsg_event_destroy(e1)
+    events.clear()
 
 
 def blur_traffic_per_launch(passes, size):
@@ -192,28 +203,14 @@ def main():
                 out, seg_d, _img, _p = gen._pipeline(None, segs[k], banks[k], {}, scale01=True)
         return out, seg_d
 
-    # per-step blur timing: HIP events (torch's current stream is the launch stream) around the 3 passes
-    from fetalsyngen_amd.generator.augmentation import synthseg as _ss
-
-    orig_blur = _ss.RandResample.blur
-    ev, passes = [], []
-
-    def timed_blur(output, stds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig_blur(output, stds)
-        e1.record()
-        ev.append((e0, e1, int(sum(1 for s in stds if s > 0))))
-        passes.extend((ax, int(np.ceil(3 * s))) for ax, s in enumerate(stds) if s > 0)
-        return r
-
-    _ss.RandResample.blur = staticmethod(timed_blur)
+    # per-step blur timing: HIP events recorded on the launch stream around the three axis passes of every
+    # sample, inside fsg_sample_run (FetalSynthGen.blur_events)
+    gen.blur_events = []
 
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize()
-    ev.clear()
-    passes.clear()
+    _drop_events(gen.blur_events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -228,10 +225,16 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    _ss.RandResample.blur = staticmethod(orig_blur)
-
-    launches = sum(n for _, _, n in ev)
-    blur_total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    lib = _lib.load()
+    launches, blur_total_ms, passes = 0, 0.0, []
+    ms = ctypes.c_float()
+    for e0, e1, pl in gen.blur_events:
+        _lib.check(lib.fsg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "fsg_event_elapsed_ms")
+        blur_total_ms += ms.value
+        launches += len(pl)
+        passes.extend(pl)
+    _drop_events(gen.blur_events)
+    gen.blur_events = None
     blur_us = blur_total_ms * 1e3 / max(launches, 1)
     achieved = 8.0 * nvox / blur_us / 1e3 if launches else 0.0  # GB/s, algorithmic 8 B/voxel/pass
 

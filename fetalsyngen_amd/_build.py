@@ -9,7 +9,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libfsg_hip.so"
-SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip"]
+SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip", "fsg_pipeline.cpp"]
 EXTRA = os.environ.get("FSG_EXTRA_FLAGS", "").split()
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -38,7 +38,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     build_dir.mkdir(exist_ok=True)
     for s in SOURCES:
         o = build_dir / (s + ".o")
-        cmd = [cc, *FLAGS, *EXTRA, "-c", str(CSRC / s), "-o", str(o)]
+        lang = ["-x", "hip"] if s.endswith(".cpp") else []
+        cmd = [cc, *FLAGS, *EXTRA, *lang, "-c", str(CSRC / s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -51,6 +51,45 @@ class Epilogue(C.Structure):
     ]
 
 
+class SamplePlan(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int32 * 3),
+        ("label_parts", C.c_void_p * 4),
+        ("mus", C.c_void_p),
+        ("sigmas", C.c_void_p),
+        ("ntab", C.c_int32),
+        ("gmm_noise", C.c_void_p),
+        ("gmm_seed", C.c_uint64),
+        ("gmm_stream", C.c_uint64),
+        ("deform_active", C.c_int32),
+        ("deform", Deform),
+        ("seg_in", C.c_void_p),
+        ("seg_out", C.c_void_p),
+        ("epi", Epilogue),
+        ("resample_active", C.c_int32),
+        ("low_shape", C.c_int32 * 3),
+        ("rs_tab", C.c_void_p * 3),
+        ("back_tab", C.c_void_p * 3),
+        ("blur_ntaps", C.c_int32 * 3),
+        ("blur_taps", (C.c_float * 129) * 3),
+        ("noise_mode", C.c_int32),
+        ("noise", C.c_void_p),
+        ("noise_seed", C.c_uint64),
+        ("noise_stream", C.c_uint64),
+        ("noise_std", C.c_float),
+        ("scale01", C.c_int32),
+        ("ws0", C.c_void_p),
+        ("ws1", C.c_void_p),
+        ("ws_low", C.c_void_p),
+        ("ws_rows", C.c_void_p),
+        ("row_stride", C.c_int32),
+        ("mm8", C.c_void_p),
+        ("out", C.c_void_p),
+        ("ev_blur_begin", C.c_void_p),
+        ("ev_blur_end", C.c_void_p),
+    ]
+
+
 P, I, F, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
 # name -> argtypes; every function returns int except where noted.  Must list EVERY symbol the
@@ -83,8 +122,12 @@ SIGNATURES = {
     "fsg_add_noise_f32": [P, SZ, P, U64, U64, F, P, P],
     "fsg_reduce_minmax_f32": [P, SZ, P, P],
     "fsg_scale_f32": [P, SZ, P, I, P, P],
+    "fsg_sample_run": [C.POINTER(SamplePlan), P],
+    "fsg_event_destroy": [P],
+    "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
 }
-SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32])}
+SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32]),
+                   "fsg_event_create": (C.c_void_p, [])}
 
 _lib = None
 

@@ -1,0 +1,122 @@
+// fsg_pipeline.cpp -- the fused per-sample launch sequence as ONE native call.
+//
+// Host-side only (no kernels here): enqueues, on the caller's stream, exactly the sequence
+// `FetalSynthGen.sample` of the reference walks through (generator/model.py:231-276: generate -> augment),
+// using the entry points declared in include/fsg_hip.h.  It exists because at ~30 us per kernel the Python
+// interpreter between launches costs as much as the kernels; semantics and results are those of calling the
+// entry points one by one (tests/test_hip_parity.py::test_native_pipeline_equals_stagewise).
+#include <hip/hip_runtime.h>
+#include "../../include/fsg_hip.h"
+
+#define FSG_TRY(expr)        \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
+  if (!p || !p->out || !p->ws0 || !p->ws1 || !p->mm8) return FSG_E_BADARG;
+  const int n0 = p->shape[0], n1 = p->shape[1], n2 = p->shape[2];
+  if (n0 <= 0 || n1 <= 0 || n2 <= 0) return FSG_E_BADARG;
+  const size_t n = (size_t)n0 * n1 * n2;
+  if (n > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  hipStream_t st = (hipStream_t)stream;
+
+  // every min/max key of the sample in one launch: [min x,y,z | zoom min] [zoom max | 3 unused]
+  FSG_TRY(fsg_minmax_init(p->mm8, 4, 4, stream));
+
+  // K1: GMM draw -> ws0
+  FSG_TRY(fsg_gmm_sample_u8x4(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
+                              p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, stream));
+  float* cur = p->ws0;
+  float* other = p->ws1;
+  const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
+
+  if (p->deform_active) {
+    // K2/K3: coarse rows, floor(min) margins; K4(+K5): fused warp of the image and the labels -> ws1
+    if (!p->seg_in || !p->seg_out) return FSG_E_BADARG;
+    fsg_deform d = p->deform;
+    const int need = 3 * d.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
+    if (p->ws_rows && need > 0 && need <= p->row_stride) {
+      d.rows = nullptr;
+      d.row_stride = 0;
+      FSG_TRY(fsg_deform_rows_f32(&d, &p->epi, p->ws_rows, p->row_stride, stream));
+      d.rows = p->ws_rows;
+      d.row_stride = p->row_stride;
+    } else {
+      d.rows = nullptr;
+      d.row_stride = 0;
+    }
+    int rc = fsg_coords_floormin_f32(&d, p->mm8, stream);
+    if (rc == FSG_E_TOOBIG) {  // coarse grid beyond the row kernels: exact min/max (6 keys) into a side buffer
+      return FSG_E_TOOBIG;     // the Python orchestration handles this rare configuration stage by stage
+    }
+    FSG_TRY(rc);
+    FSG_TRY(fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream));
+    float* t = cur; cur = other; other = t;
+  } else {
+    if (has_gamma) {
+      FSG_TRY(fsg_gamma_f32(cur, n, p->epi.gamma, other, stream));
+      float* t = cur; cur = other; other = t;
+    }
+    if (has_bias) {
+      FSG_TRY(fsg_bias_mul_f32(cur, n0, n1, n2, p->epi.bias, p->epi.bias_dims[0], p->epi.bias_dims[1],
+                               p->epi.bias_dims[2], p->epi.bx, p->epi.by, p->epi.bz, other, stream));
+      float* t = cur; cur = other; other = t;
+    }
+  }
+
+  if (p->resample_active) {
+    // K6: separable blur, x then y then z (optionally bracketed by the caller's HIP events: bench.py's live
+    // measurement of the graded kernel on the launch stream)
+    if (p->ev_blur_begin && hipEventRecord((hipEvent_t)p->ev_blur_begin, st) != hipSuccess) return FSG_E_BADARG;
+    for (int axis = 0; axis < 3; ++axis) {
+      const int nt = p->blur_ntaps[axis];
+      if (nt <= 0) continue;
+      int rc = fsg_blur_axis_taps_host_f32(cur, other, n0, n1, n2, axis, p->blur_taps[axis], nt, stream);
+      if (rc == FSG_E_ALIGN) return FSG_E_ALIGN;  // shape outside the tuned kernels: stage-by-stage path
+      FSG_TRY(rc);
+      float* t = cur; cur = other; other = t;
+    }
+    if (p->ev_blur_end && hipEventRecord((hipEvent_t)p->ev_blur_end, st) != hipSuccess) return FSG_E_BADARG;
+    // K7+K8: resample + noise -> low;  K9 (+K10): min/max of the zoom-back, then zoom-back + normalise -> out
+    if (!p->ws_low) return FSG_E_BADARG;
+    const int m0 = p->low_shape[0], m1 = p->low_shape[1], m2 = p->low_shape[2];
+    FSG_TRY(fsg_resample_noise_f32(cur, n0, n1, n2, p->rs_tab[0], p->rs_tab[1], p->rs_tab[2], p->ws_low, m0, m1, m2,
+                                   p->noise_mode, p->noise, p->noise_seed, p->noise_stream, p->noise_std, stream));
+    FSG_TRY(fsg_zoom3d_minmax_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1, n2,
+                                  p->mm8 + 3, stream));
+    FSG_TRY(fsg_zoom3d_normalise_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out, n0,
+                                     n1, n2, p->mm8 + 3, p->scale01 ? 1 : 0, stream));
+    return 0;
+  }
+
+  // no resampling: noise at full resolution, optional [0,1] scaling
+  if (p->noise_mode != 0) {
+    float* dst = p->scale01 ? other : p->out;
+    FSG_TRY(fsg_add_noise_f32(cur, n, p->noise_mode == 1 ? p->noise : nullptr, p->noise_seed, p->noise_stream,
+                              p->noise_std, dst, stream));
+    cur = dst;
+  }
+  if (p->scale01) {
+    FSG_TRY(fsg_reduce_minmax_f32(cur, n, p->mm8 + 3, stream));
+    FSG_TRY(fsg_scale_f32(cur, n, p->mm8 + 3, 1, p->out, stream));
+  } else if (cur != p->out) {
+    hipError_t e = hipMemcpyAsync(p->out, cur, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// Thin hipEvent helpers so a ctypes caller can time sections of fsg_sample_run on the launch stream.
+extern "C" void* fsg_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" int fsg_event_destroy(void* e) { return e ? (int)hipEventDestroy((hipEvent_t)e) : FSG_E_BADARG; }
+extern "C" int fsg_event_elapsed_ms(void* begin, void* end, float* ms) {
+  if (!begin || !end || !ms) return FSG_E_BADARG;
+  hipError_t rc = hipEventSynchronize((hipEvent_t)end);
+  if (rc != hipSuccess) return (int)rc;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end);
+}

@@ -69,6 +69,9 @@ class FetalSynthGen:
         }
         self.device = device
         self.rng = rng  # None: module default (fetalsyngen_amd.rng.get_mode())
+        self.native_pipeline = True  # one fsg_sample_run call per sample when the inputs allow it
+        self.blur_events = None      # set to a list to have HIP events recorded around each sample's blur passes
+        self._ws = {}
 
     def prewarm(self, shape=None) -> int:
         """Build and upload every per-axis table this configuration can ask for (the low-res size of
@@ -92,6 +95,114 @@ class FetalSynthGen:
                     K._device_table(T.zoom_table(s_, float(np.float64(size) / np.float64(s_)), size), self.device)
                     n += 1
         return n
+
+    # ---- native fused path -------------------------------------------------------------------------
+    def _workspace(self, shape, need_rows):
+        """Per (shape, stream) scratch volumes, reused by consecutive samples on that stream."""
+        dev = torch.device(self.device)
+        key = (shape, dev.index, K._stream(dev).value)
+        ws = self._ws.get(key)
+        n = int(np.prod(shape))
+        if ws is None:
+            ws = {"ws0": torch.empty(n, dtype=torch.float32, device=dev),
+                  "ws1": torch.empty(n, dtype=torch.float32, device=dev),
+                  "low": torch.empty(n, dtype=torch.float32, device=dev),
+                  "mm8": torch.empty(8, dtype=torch.int32, device=dev), "rows": None, "stride": 0}
+            if len(self._ws) >= 4:
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[key] = ws
+        if need_rows > ws["stride"]:
+            ws["stride"] = (max(need_rows, 64) + 3) // 4 * 4
+            ws["rows"] = torch.empty(shape[0] * shape[1] * ws["stride"], dtype=torch.float32, device=dev)
+        return ws
+
+    def _run_native(self, shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev, bias_tabs,
+                    rplan, rs_tabs, back_tabs, nplan, scale01):
+        """Fill a fsg_sample_plan and enqueue the whole sample with one call.  Returns (image, labels), or None
+        when the configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
+        import ctypes as C
+
+        from .. import _lib
+
+        dev = torch.device(self.device)
+        seg = segmentation.to(dev)
+        if seg.dtype != torch.float32:
+            seg = seg.float()
+        seg = seg.contiguous()
+        f2 = int(spec.c.field_dims[2]) if spec is not None else 0
+        b2 = int(bias_dev.shape[2]) if bias_dev is not None else 0
+        ws = self._workspace(shape, 3 * f2 + b2 if spec is not None else 0)
+        p = _lib.SamplePlan()
+        p.shape[:] = shape
+        for q, part in enumerate(label_parts):
+            p.label_parts[q] = part.data_ptr()
+        p.mus, p.sigmas, p.ntab = mus.data_ptr(), sigmas.data_ptr(), int(mus.numel())
+        f = gmm_plan.field
+        keep = [seg]
+        if f.host is not None:
+            z = f.device_tensor(dev)
+            keep.append(z)
+            p.gmm_noise = z.data_ptr()
+        else:
+            p.gmm_seed, p.gmm_stream = f.seed, f.stream_id
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        seg_out = seg
+        if spec is not None:
+            p.deform_active = 1
+            p.deform = spec.c
+            seg_out = torch.empty_like(seg)
+            p.seg_in, p.seg_out = seg.data_ptr(), seg_out.data_ptr()
+        p.epi = K._epilogue(gam, bias_dev, bias_tabs, shape)
+        if rplan.active:
+            p.resample_active = 1
+            p.low_shape[:] = rplan.new_size
+            for a_, (t1, t2) in enumerate(zip(rs_tabs.ptrs, back_tabs.ptrs)):
+                p.rs_tab[a_], p.back_tab[a_] = t1.value, t2.value
+            for a_ in range(3):
+                if rplan.stds[a_] > 0:
+                    taps = T.gaussian_taps(float(rplan.stds[a_]))
+                    if len(taps) > 129:
+                        return None
+                    p.blur_ntaps[a_] = len(taps)
+                    C.memmove(p.blur_taps[a_], taps.ctypes.data, taps.nbytes)
+        if nplan.active:
+            nf = nplan.field
+            p.noise_std = nplan.std32
+            if nf.host is not None:
+                zn = nf.device_tensor(dev)
+                keep.append(zn)
+                p.noise_mode, p.noise = 1, zn.data_ptr()
+            else:
+                p.noise_mode, p.noise_seed, p.noise_stream = 2, nf.seed, nf.stream_id
+        p.scale01 = int(bool(scale01))
+        p.ws0, p.ws1, p.ws_low = ws["ws0"].data_ptr(), ws["ws1"].data_ptr(), ws["low"].data_ptr()
+        if ws["rows"] is not None:
+            p.ws_rows, p.row_stride = ws["rows"].data_ptr(), ws["stride"]
+        p.mm8 = ws["mm8"].data_ptr()
+        p.out = out.data_ptr()
+        if self.blur_events is not None and rplan.active:  # (begin, end, n_passes) appended per sample
+            lib = _lib.load()
+            e0, e1 = lib.fsg_event_create(), lib.fsg_event_create()
+            p.ev_blur_begin, p.ev_blur_end = e0, e1
+            self.blur_events.append((e0, e1, [(a_, int(p.blur_ntaps[a_]) // 2) for a_ in range(3) if p.blur_ntaps[a_]]))
+        rc = _lib.load().fsg_sample_run(C.byref(p), K._stream(dev))
+        if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
+            return None
+        _lib.check(rc, "fsg_sample_run")
+        return out, seg_out
+
+    @staticmethod
+    def _params(selected_seeds, seed_intensities, dplan, g, bplan, rplan, nplan, artifacts):
+        return {
+            "selected_seeds": selected_seeds,
+            "seed_intensities": seed_intensities,
+            "deform_params": dplan.params,
+            "gamma_params": {"gamma": g},
+            "bf_params": bplan.params,
+            "resample_params": {"spacing": rplan.spacing.tolist() if rplan.active else None},
+            "noise_params": {"noise_std": nplan.std32 if nplan.active else None},
+            "artifacts": artifacts,
+        }
 
     def _validated_genparams(self, d):
         if not isinstance(d, dict):
@@ -213,6 +324,21 @@ class FetalSynthGen:
             seed_intensities = {}
             if gmm_plan is not None:
                 mus, sigmas = f32_view(gm_off[0], (gm_off[2],)), f32_view(gm_off[1], (gm_off[2],))
+                seed_intensities = {"mus": mus, "sigmas": sigmas}
+            bias_dev = f32_view(bias_off, tuple(bplan.grid.shape)) if bplan.active else None
+            gam = float(g) if g is not None else None
+            has_art = any(a is not None for a in self.artifacts.values())
+            spec = sb.build() if dplan.active else None
+
+            if (self.native_pipeline and label_parts is not None and image is None and not has_art
+                    and segmentation_u8 is None):
+                native = self._run_native(shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev,
+                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01)
+                if native is not None:
+                    return native[0], native[1], None, self._params(selected_seeds, seed_intensities, dplan, g, bplan,
+                                                                    rplan, nplan, {})
+
+            if gmm_plan is not None:
                 f = gmm_plan.field
                 z = f.device_tensor(dev) if f.host is not None else None
                 if label_parts is not None:
@@ -223,17 +349,12 @@ class FetalSynthGen:
                         labels = labels.long()
                     labels = labels.to(dev).contiguous()
                     output = K.gmm_sample(labels, mus, sigmas, noise=z, seed=f.seed or 0, stream_id=f.stream_id)
-                seed_intensities = {"mus": mus, "sigmas": sigmas}
             else:
                 output = self._intensity_prior(image)
-
-            bias_dev = f32_view(bias_off, tuple(bplan.grid.shape)) if bplan.active else None
-            gam = float(g) if g is not None else None
             image = image.to(dev) if image is not None else None
             # one init launch for every min/max key of the sample: [min x,y,z | zoom min] [zoom max | unused x3]
             mm8 = K.new_minmax(dev, 4, 4)
             if dplan.active:
-                spec = sb.build()
                 image, segmentation, output = sd.run(dplan, image, segmentation, output, spec=spec,
                                                      mm6=K.coords_floormin(spec, mm8), gamma=gam, bias=bias_dev,
                                                      bias_tabs=bias_tabs, segmentation_u8=segmentation_u8)
@@ -244,7 +365,6 @@ class FetalSynthGen:
                 if bplan.active:
                     output = K.bias_mul(output, bias_dev, bias_tabs)
 
-            has_art = any(a is not None for a in self.artifacts.values())
             fuse_scale = scale01 and not has_art
             f = nplan.field if nplan.active else None
             z = f.device_tensor(dev) if (f is not None and f.host is not None) else None
@@ -264,14 +384,5 @@ class FetalSynthGen:
             if scale01 and has_art:
                 output = K.scale(output.contiguous(), K.reduce_minmax(output.contiguous()), mode=1)
 
-        synth_params = {
-            "selected_seeds": selected_seeds,
-            "seed_intensities": seed_intensities,
-            "deform_params": dplan.params,
-            "gamma_params": {"gamma": g},
-            "bf_params": bplan.params,
-            "resample_params": {"spacing": rplan.spacing.tolist() if rplan.active else None},
-            "noise_params": {"noise_std": nplan.std32 if nplan.active else None},
-            "artifacts": artifacts,
-        }
+        synth_params = self._params(selected_seeds, seed_intensities, dplan, g, bplan, rplan, nplan, artifacts)
         return output, segmentation, image, synth_params

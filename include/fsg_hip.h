@@ -207,6 +207,59 @@ int fsg_scale_f32(const float* x, size_t n, const int32_t* mm, int mode, float* 
 /* Decode ordered keys on the host side helper (pure function, no GPU). */
 float fsg_key_to_float(int32_t key);
 
+/* ---- whole-sample launch sequence -------------------------------------------------------------------------- */
+/* One call = the fused kernel sequence of FetalSynthGen.sample (generator/model.py:231-276) for the
+ * seeds-based path: GMM draw -> [rows, margins, warp(+gamma+bias, labels)] -> [blur x,y,z, resample+noise,
+ * zoom-back min/max, zoom-back+normalise] on `stream`.  All random quantities are inputs (drawn by the host in
+ * the reference's order).  Workspaces are caller-owned and may be reused by the next call on the same stream.
+ * Returns FSG_E_ALIGN / FSG_E_TOOBIG for configurations the fused kernels do not cover (the caller then issues
+ * the entry points above one by one). */
+typedef struct fsg_sample_plan {
+  int32_t shape[3];
+  /* K1 */
+  const uint8_t* label_parts[4]; /* per-meta-label seed volumes (disjoint supports), [1..3] may be NULL      */
+  const float* mus;
+  const float* sigmas;
+  int32_t ntab;
+  const float* gmm_noise;        /* NULL: Philox(gmm_seed, gmm_stream)                                       */
+  uint64_t gmm_seed, gmm_stream;
+  /* K2..K5 */
+  int32_t deform_active;
+  fsg_deform deform;             /* rows / row_stride are filled in by the call                              */
+  const float* seg_in;           /* float32 label volume and its deformed copy (deform_active only)          */
+  float* seg_out;
+  fsg_epilogue epi;              /* gamma <= 0: off; bias NULL: off (applied stand-alone when not deforming)  */
+  /* K6..K8 */
+  int32_t resample_active;
+  int32_t low_shape[3];
+  const fsg_tap* rs_tab[3];      /* full -> low resolution tables                                            */
+  const fsg_tap* back_tab[3];    /* low -> full resolution tables                                            */
+  int32_t blur_ntaps[3];         /* 0: axis not blurred                                                      */
+  float blur_taps[3][129];
+  int32_t noise_mode;            /* 0 none, 1 `noise` pointer, 2 Philox(noise_seed, noise_stream)            */
+  const float* noise;
+  uint64_t noise_seed, noise_stream;
+  float noise_std;
+  /* K9/K10 */
+  int32_t scale01;               /* 1: also apply the dataset's [0,1] scaling (data/datasets.py:311)         */
+  /* workspaces + result */
+  float* ws0;                    /* shape[] floats each                                                       */
+  float* ws1;
+  float* ws_low;                 /* >= prod(low_shape) floats                                                 */
+  float* ws_rows;                /* shape[0]*shape[1]*row_stride floats, or NULL                              */
+  int32_t row_stride;
+  int32_t* mm8;                  /* 8 x int32                                                                 */
+  float* out;                    /* shape[] floats                                                            */
+  void* ev_blur_begin;           /* optional hipEvent_t pair recorded around the blur passes (fsg_event_*)     */
+  void* ev_blur_end;
+} fsg_sample_plan;
+int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
+
+/* hipEvent helpers for ctypes callers (timing on the launch stream). elapsed_ms synchronises on `end`. */
+void* fsg_event_create(void);
+int fsg_event_destroy(void* event);
+int fsg_event_elapsed_ms(void* begin, void* end, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -673,3 +673,42 @@ def test_genparams_replay_fixes_the_augmentation_strengths(K):
     assert p3["deform_params"] == {"affine": None, "non_rigid": None, "flip": False}
     assert p3["gamma_params"]["gamma"] is None and p3["resample_params"]["spacing"] is None
     assert np.array_equal(host(seg3), seg)
+
+
+@pytest.mark.parametrize("rng_mode", ["reference", "device"])
+@pytest.mark.parametrize("prob", [1.0, 0.5, 0.0])
+def test_native_pipeline_equals_stagewise(K, rng_mode, prob):
+    """fsg_sample_run (one native call per sample, device-resident SeedBank) must give bit-identical images
+    and labels to launching the entry points one by one from Python, for every gate combination."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (48, 40, 32)
+    seg, seeds = make_seed_volumes(shape, 1)
+    bank = SeedBank(seeds, DEV)
+    segd = dev(seg)
+    for seed in range(6):
+        res = {}
+        for native in (True, False):
+            gen = make_generator(shape, DEV, rng=rng_mode, prob=prob, nonlin_scale=(0.1, 0.25), bf_scale=(0.05, 0.15))
+            gen.native_pipeline = native
+            for scale01 in (True, False):
+                np.random.seed(seed)
+                torch.manual_seed(seed)
+                out, lab, img, params = gen._pipeline(None, segd, bank, {}, scale01=scale01)
+                res[(native, scale01)] = (host(out), host(lab), params)
+        for scale01 in (True, False):
+            a, b = res[(True, scale01)], res[(False, scale01)]
+            assert np.array_equal(a[0], b[0]), (seed, scale01)
+            assert np.array_equal(a[1], b[1]), (seed, scale01)
+            assert a[2]["gamma_params"] == b[2]["gamma_params"] and a[2]["noise_params"] == b[2]["noise_params"]
+            assert a[2]["resample_params"] == b[2]["resample_params"]
+    # and the host-array seeds path (reference-style dict of volumes) agrees with the SeedBank path
+    gen = make_generator(shape, DEV, rng=rng_mode, prob=prob, nonlin_scale=(0.1, 0.25), bf_scale=(0.05, 0.15))
+    np.random.seed(3)
+    torch.manual_seed(3)
+    o1, l1, _, _ = gen._pipeline(None, t(seg), seeds, {}, scale01=True)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    o2, l2, _, _ = gen._pipeline(None, segd, bank, {}, scale01=True)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
