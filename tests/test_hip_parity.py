@@ -712,3 +712,139 @@ def test_native_pipeline_equals_stagewise(K, rng_mode, prob):
     torch.manual_seed(3)
     o2, l2, _, _ = gen._pipeline(None, segd, bank, {}, scale01=True)
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
+
+
+# ---- BASELINE.json configs as parity cases ------------------------------------------------------------
+def test_config1_sta21_128_on_gpu(K, golden):
+    """BASELINE config 1 (sub-sta21 at 128^3, seed 0, YAML probabilities): the HIP path against what the real
+    reference produced on the CPU (fixture holds the decimated inputs and summaries of the output)."""
+    g = golden("config1_sta21_128")
+    comb = g["seeds_in"].astype(np.int8)
+    zero = np.zeros_like(comb)
+    seeds = {n: {m: (comb if m == 1 else zero) for m in range(1, 5)} for n in range(1, 7)}
+    shape = (128, 128, 128)
+    for bank in (False, True):
+        gen = make_generator(shape, DEV, rng="reference", prob=0.9, resolution=(1.0, 1.0, 1.0), res_range=(1.0, 3.0))
+        src = seeds
+        if bank:
+            from fetalsyngen_amd.data.datasets import SeedBank
+
+            src = SeedBank(seeds, DEV)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        out, seg, _img, params = gen._pipeline(None, dev(g["seg_in"].astype(np.float32)), src, {}, scale01=True)
+        m2s = params["selected_seeds"]["mlabel2subclusters"]
+        assert [m2s[m] for m in range(1, 5)] == list(g["mlabel2subclusters"])
+        so = host(seg).astype(np.uint8)
+        assert np.array_equal(np.bincount(so.reshape(-1), minlength=8), g["label_counts"])
+        assert np.array_equal(so[::4, ::4, ::4], g["seg_sub4"])
+        assert np.array_equal(so[64], g["seg_slice_x"]) and np.array_equal(so[:, :, 64], g["seg_slice_z"])
+        sc = host(out)
+        np.testing.assert_allclose(sc[::8, ::8, ::8], g["sub8"], rtol=0, atol=2e-5)
+        st = np.array([sc.min(), sc.max(), sc.mean(dtype=np.float64), sc.std(dtype=np.float64)])
+        np.testing.assert_allclose(st, g["stats"], rtol=1e-5, atol=1e-6)
+
+
+def test_config3_batch_is_independent_of_the_sharding(K):
+    """BASELINE config 3 in miniature: a batch of volumes produced under (base_seed, index) keys gives the
+    same volumes whether one rank makes all of them or they are dealt round-robin to 2 / 4 ranks."""
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (32, 32, 32)
+    n_items = 8
+    banks, segs = [], []
+    for v in range(4):
+        seg, seeds = make_seed_volumes(shape, v)
+        banks.append(SeedBank(seeds, DEV))
+        segs.append(dev(seg))
+
+    def produce(i):
+        gen = make_generator(shape, DEV, rng="device", prob=0.9, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+        sharding.seed_for_sample(2024, i)
+        out, seg, _, _ = gen._pipeline(None, segs[i % 4], banks[i % 4], {}, scale01=True)
+        return host(out), host(seg)
+
+    ref = [produce(i) for i in range(n_items)]
+    for world in (2, 4):
+        got = {}
+        for rank in range(world):
+            for i in sharding.shard(n_items, rank, world):
+                got[i] = produce(i)
+        for i in range(n_items):
+            assert np.array_equal(got[i][0], ref[i][0]) and np.array_equal(got[i][1], ref[i][1])
+    assert not np.array_equal(ref[0][0], ref[4][0])  # same label volume, different key -> different sample
+
+
+def test_config4_384_hot_path_properties(K):
+    """BASELINE config 4 grid (384^3, 0.5 mm): the hot path beyond the Infinity-Cache-resident size.  Checked
+    through size-independent properties (a full oracle run at 384^3 takes minutes on the host):
+    labels are a pure gather of the input labels, the [0,1] image spans exactly [0,1], the no-deformation /
+    no-augmentation run reproduces the GMM draw, and the result is deterministic."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (384, 384, 384)
+    seg, seeds = make_seed_volumes(shape)
+    bank = SeedBank(seeds, DEV)
+    segd = dev(seg)
+    gen = make_generator(shape, DEV, rng="device", prob=1.0)
+    outs = []
+    for rep in range(2):
+        np.random.seed(5)
+        torch.manual_seed(5)
+        out, lab, _, params = gen._pipeline(None, segd, bank, {}, scale01=True)
+        outs.append((out, lab))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    out, lab = outs[0]
+    assert float(out.min()) == 0.0 and float(out.max()) == 1.0 and bool(torch.isfinite(out).all())
+    assert set(torch.unique(lab).tolist()) <= set(np.unique(seg).tolist())
+    frac = float((lab > 0).float().mean())
+    assert 0.5 * float((segd > 0).float().mean()) < frac < 1.6 * float((segd > 0).float().mean())
+    assert params["deform_params"]["non_rigid"]["size_F_small"][0] in range(11, 25)
+    # the oracle on a coarse sub-lattice of the SAME deformation: labels at every 16th voxel must match exactly
+    spec_params = params["deform_params"]
+    A = O.affine_matrix(spec_params["affine"]["rotations"], spec_params["affine"]["shears"], spec_params["affine"]["scalings"])
+    assert A.shape == (3, 3)
+    lazy = make_generator(shape, DEV, rng="device", prob=0.0)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    raw, lab0, _, p0 = lazy._pipeline(None, segd, bank, {}, scale01=False)
+    assert torch.equal(lab0, segd)
+    m2s = p0["selected_seeds"]["mlabel2subclusters"]
+    mus, sig = p0["seed_intensities"]["mus"], p0["seed_intensities"]["sigmas"]
+    cnt, mean, var = K.label_stats(bank.combined(m2s), raw, 50)
+    for l in torch.nonzero(cnt > 200000).flatten().tolist():
+        if float(mus[l]) > 4 * float(sig[l]):
+            assert abs(float(mean[l]) - float(mus[l])) < 0.05 and abs(float(var[l]) ** 0.5 - float(sig[l])) < 0.05
+
+
+def test_config5_streaming_epoch_through_a_dataloader(K, tmp_path):
+    """BASELINE config 5 in miniature: an epoch streamed through a torch DataLoader consumer (main-process
+    producer, device-resident outputs and reference-contract CPU outputs)."""
+    from tests.util_bids import write_tree
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import FetalSynthDataset
+
+    shape = (32, 32, 32)
+    bids, seed_dir = write_tree(tmp_path, shape, ["sub-a", "sub-b", "sub-c"])
+    for return_device in (False, True):
+        gen = make_generator(shape, DEV, rng="device", prob=0.9, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+        ds = FetalSynthDataset(str(bids), gen, str(seed_dir), None, return_device=return_device)
+        stream = sharding.ShardedSynthStream(lambda i: ds[i % len(ds)], n_items=12, base_seed=3, rank=0, world=1)
+        loader = torch.utils.data.DataLoader(stream, batch_size=4, num_workers=0)
+        seen, total = 0, 0.0
+        for batch in loader:
+            assert batch["image"].shape == (4, 1, *shape)
+            assert batch["image"].is_cuda == return_device
+            assert batch["label"].dtype == (torch.uint8 if return_device else torch.int64)
+            total += float(batch["image"].sum())
+            seen += batch["image"].shape[0]
+        assert seen == 12 and np.isfinite(total)
+        # restartable: the same (base_seed, index) gives the same sample
+        sharding.seed_for_sample(3, 7)
+        a = ds[7 % len(ds)]["image"]
+        sharding.seed_for_sample(3, 7)
+        b = ds[7 % len(ds)]["image"]
+        assert torch.equal(a, b)
