@@ -174,6 +174,8 @@ def main():
     _lib.load()  # fail loudly if the HIP library is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
+    if os.environ.get("FSG_BENCH_SHARE_GPU0"):  # rehearsal of the N>1 path on a 1-GPU box: every rank on cuda:0
+        local = 0
     device = f"cuda:{local}"
     torch.cuda.set_device(device)
     shape = (args.size,) * 3
