@@ -1,0 +1,109 @@
+"""Output side of the path: getting samples to the host without stalling the generator.
+
+The reference's dataset ends every sample with `.cpu()` on the image and the labels (data/datasets.py:315-317)
+-- a synchronous pageable copy of 64 MiB + (after `.long()`) 128 MiB at 256^3 that idles the GPU.  `HostStager`
+keeps a ring of PINNED host buffers; a sample's device tensors are copied on a side stream while the next
+samples are being generated, and handed out when their copy event has completed.  `PrefetchingStream` drives a
+`FetalSynthDataset` that way (BASELINE config 5: streaming epoch into a DataLoader-style consumer).
+"""
+from __future__ import annotations
+
+from collections import deque
+
+import torch
+
+from .. import sharding
+
+
+class HostStager:
+    def __init__(self, shape, device, depth: int = 3, label_dtype=torch.int64):
+        self.device = torch.device(device)
+        self.depth = depth
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = []
+        for _ in range(depth):
+            self.slots.append({
+                "image": torch.empty((1, *shape), dtype=torch.float32, pin_memory=True),
+                "label": torch.empty((1, *shape), dtype=label_dtype, pin_memory=True),
+                "event": torch.cuda.Event(),
+                "busy": False,
+            })
+        self._next = 0
+        self.label_dtype = label_dtype
+
+    def submit(self, image_dev: torch.Tensor, label_dev: torch.Tensor) -> int:
+        """Enqueue the D2H copies of one sample; returns a ticket for `collect`."""
+        slot_id = self._next
+        slot = self.slots[slot_id]
+        if slot["busy"]:
+            raise RuntimeError("HostStager ring overrun: collect() a ticket before submitting more than `depth`")
+        self._next = (self._next + 1) % self.depth
+        produced = torch.cuda.Event()
+        produced.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(produced)
+            lab = label_dev if label_dev.dtype == self.label_dtype else label_dev.to(self.label_dtype)
+            slot["image"].view(image_dev.shape).copy_(image_dev, non_blocking=True)
+            slot["label"].view(lab.shape).copy_(lab, non_blocking=True)
+            # the device tensors must outlive the copy although their Python references may not
+            image_dev.record_stream(self.copy_stream)
+            lab.record_stream(self.copy_stream)
+            slot["event"].record(self.copy_stream)
+        slot["busy"] = True
+        return slot_id
+
+    def collect(self, ticket: int, clone: bool = False):
+        """Wait for the sample's copies; returns (image, label) views of the pinned slot (valid until the slot
+        is submitted again) or private copies when `clone`."""
+        slot = self.slots[ticket]
+        slot["event"].synchronize()
+        slot["busy"] = False
+        if clone:
+            return slot["image"].clone(), slot["label"].clone()
+        return slot["image"], slot["label"]
+
+
+class PrefetchingStream:
+    """Iterates `indices` of a FetalSynthDataset keeping `depth` samples in flight.
+
+    to_host=True : yields the reference contract (image float32 (1,H,W,D) and int64 labels on the CPU, pinned)
+    to_host=False: yields device-resident tensors (float32 image, uint8 labels)."""
+
+    def __init__(self, dataset, indices, base_seed: int = 0, depth: int = 3, to_host: bool = True,
+                 label_dtype=torch.int64):
+        self.ds, self.indices, self.base_seed, self.depth, self.to_host = dataset, list(indices), base_seed, depth, to_host
+        self.label_dtype = label_dtype
+        self._stager = None
+
+    def __len__(self):
+        return len(self.indices)
+
+    def _produce(self, i):
+        sharding.seed_for_sample(self.base_seed, i)
+        idx = i % len(self.ds)
+        segm = self.ds._segmentation(idx)
+        name = self.ds._sub_ses_idx(idx)
+        seeds = self.ds._seeds_for(name)
+        out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True)
+        return out, seg, name
+
+    def __iter__(self):
+        if not self.to_host:
+            for i in self.indices:
+                out, seg, name = self._produce(i)
+                yield {"image": out.unsqueeze(0), "label": seg.to(torch.uint8).unsqueeze(0), "name": name}
+            return
+        pending = deque()
+        for i in self.indices:
+            out, seg, name = self._produce(i)
+            if self._stager is None:
+                self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype)
+            if len(pending) >= self.depth:
+                t, n = pending.popleft()
+                img, lab = self._stager.collect(t)
+                yield {"image": img, "label": lab, "name": n}
+            pending.append((self._stager.submit(out, seg), name))
+        while pending:
+            t, n = pending.popleft()
+            img, lab = self._stager.collect(t)
+            yield {"image": img, "label": lab, "name": n}
