@@ -7,8 +7,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libfsg_hip.so"
+LIB_PATH = Path(os.environ.get("FSG_LIB", PKG / "libfsg_hip.so"))  # FSG_LIB: A/B another build of the same ABI
 
 E_BADARG, E_TOOBIG, E_ALIGN = -1, -2, -3
 

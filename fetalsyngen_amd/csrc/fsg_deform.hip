@@ -529,6 +529,95 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
   }
 }
 
+// ---- lean per-voxel body on buffer addressing (patch kernel) ------------------------------------------------
+// The patch kernel is instruction-issue bound (~290 wave-instructions per 64 voxels, one per quad-cycle per
+// SIMD; profiles/r01_pmc_warp.md), so this body spends as few instructions as the arithmetic allows:
+//   * raw buffer loads (SGPR descriptor + 32-bit byte offset): no 64-bit address arithmetic, and out-of-range
+//     offsets return 0 instead of faulting, so no index is ever clamped (indices are in range by construction;
+//     the clamp only guarded against NaN positions);
+//   * ONE base offset per voxel; the 2x2x2 neighbours are base +- plane stride, + row stride, and the upper z
+//     neighbour is the second half of each 8-byte load.  Where the reference clamps a neighbour onto the base
+//     (coordinate exactly on the last plane/row/column) its weight is exactly 0, so whichever finite value (or
+//     the 0 of an out-of-range read) sits there contributes +-0: same result.  Only the z edge is re-read with
+//     4-byte loads, because the 8-byte load of the buffer's very last element would straddle its end.
+struct WarpBuf {
+  __amdgpu_buffer_rsrc_t lin, nn;
+  unsigned sx, sy;   // element strides of x and y
+  int dx_bytes;      // +-plane stride in bytes (sign: flip)
+};
+
+template <typename LT>
+__device__ __forceinline__ LT buf_load_label(__amdgpu_buffer_rsrc_t r, unsigned elem);
+template <>
+__device__ __forceinline__ float buf_load_label<float>(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, elem * 4u, 0, 0));
+}
+template <>
+__device__ __forceinline__ uint8_t buf_load_label<uint8_t>(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_amdgcn_raw_buffer_load_b8(r, elem, 0, 0);
+}
+
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
+__device__ __forceinline__ void warp_emit_buf(const FsgDeformK& D, const EpiK& E, const Margins& m, const WarpBuf& B,
+                                              const float* sm, int nf, int i, int j, int k, bool live,
+                                              const fsg_tap& c, const fsg_tap& cb, size_t row,
+                                              float* __restrict__ out_lin, LT* __restrict__ out_nn) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  float x, y, z;
+  row_position(D, sm, i, j, k, c, x, y, z);
+  x = x - m.mx;
+  y = y - m.my;
+  z = z - m.mz;
+  if (HAS_NN) {
+    int xi = (int)rintf(x);
+    const int yi = (int)rintf(y), zi = (int)rintf(z);
+    if (D.flip) xi = D.n0 - 1 - xi;
+    const LT l = buf_load_label<LT>(B.nn, (unsigned)xi * B.sx + (unsigned)yi * B.sy + (unsigned)zi);
+    if (live) out_nn[row + k] = l;
+  }
+  if (HAS_LIN) {
+    const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f);  // x <= n-1 etc. hold by construction (clamped)
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    int x0 = (int)fx;
+    const int y0 = (int)fy, z0 = (int)fz;
+    const float bx = x - fx, by = y - fy, bz = z - fz;
+    const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
+    if (D.flip) x0 = D.n0 - 1 - x0;
+    const unsigned o = ((unsigned)x0 * B.sx + (unsigned)y0 * B.sy + (unsigned)z0) * 4u;
+    const unsigned oy = B.sy * 4u;
+    f2v p00 = {0.f, 0.f}, p10 = {0.f, 0.f}, p01 = {0.f, 0.f}, p11 = {0.f, 0.f};
+    if (ok) {  // voxels that sample outside the volume (clamped onto a 0-face) need no data
+      p00 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(B.lin, o, 0, 0));
+      p10 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(B.lin, o + (unsigned)B.dx_bytes, 0, 0));
+      p01 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(B.lin, o + oy, 0, 0));
+      p11 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(B.lin, o + (unsigned)B.dx_bytes + oy, 0, 0));
+    }
+    if (ok && z0 >= D.n2 - 1) {  // rare (z exactly on the last column): single-element reads, upper neighbour unused
+      p00.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(B.lin, o, 0, 0));
+      p10.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(B.lin, o + (unsigned)B.dx_bytes, 0, 0));
+      p01.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(B.lin, o + oy, 0, 0));
+      p11.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(B.lin, o + (unsigned)B.dx_bytes + oy, 0, 0));
+      p00.y = p00.x; p10.y = p10.x; p01.y = p01.x; p11.y = p11.x;
+    }
+    const float c00 = p00.x * ax + p10.x * bx;
+    const float c01 = p00.y * ax + p10.y * bx;
+    const float c10 = p01.x * ax + p11.x * bx;
+    const float c11 = p01.y * ax + p11.y * bx;
+    const float c0 = c00 * ay + c10 * by;
+    const float c1 = c01 * ay + c11 * by;
+    float v = ok ? (c0 * az + c1 * bz) : 0.f;
+    if (E.gamma > 0.f) {
+      if (FAST) v = 300.0f * __builtin_amdgcn_exp2f(E.gamma * (__builtin_amdgcn_logf(v) - 8.2288186904958804f));
+      else v = 300.0f * powf(v / 300.0f, E.gamma);
+    }
+    if (E.bias) {
+      const float bval = fsg_mix(cb.w_lo, sm[nf + cb.lo], cb.w_hi, sm[nf + cb.hi]);
+      v = v * (FAST ? __builtin_amdgcn_exp2f(bval * 1.4426950408889634f) : expf(bval));
+    }
+    if (live) out_lin[row + k] = v;
+  }
+}
+
 // ---- patch variant: 16 waves sweep a 4 x 4 patch of adjacent rows in lockstep ----------------------------
 // Cost model (profiles/r01_gather_cost_ubench.txt): a gather costs ~10.7 cycles of the CU's fill path per
 // 128-B line that misses L1, whatever its width.  Output rows (i..i+3, j..j+3) read source rows that
@@ -538,7 +627,7 @@ __global__ __launch_bounds__(256) void warp_rows_kernel(FsgDeformK D, const int3
 constexpr int PATCH = 4;
 constexpr int PATCH_ROWCAP = 128;
 
-template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST>
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST, bool BUF>
 __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
                                                           const float* __restrict__ src_lin,
                                                           float* __restrict__ out_lin,
@@ -564,14 +653,29 @@ __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const
   }
   wave_lds_sync();
   const size_t row = ((size_t)i * D.n1 + j) * D.n2;
+  const unsigned nvox = (unsigned)D.n0 * (unsigned)D.n1 * (unsigned)D.n2;
+  WarpBuf B;
+  B.lin = __builtin_amdgcn_make_buffer_rsrc((void*)src_lin, 0, HAS_LIN ? nvox * 4u : 0u, 0x00020000);
+  B.nn = __builtin_amdgcn_make_buffer_rsrc((void*)src_nn, 0, HAS_NN ? nvox * (unsigned)sizeof(LT) : 0u, 0x00020000);
+  B.sy = (unsigned)D.n2;
+  B.sx = (unsigned)D.n1 * (unsigned)D.n2;
+  B.dx_bytes = D.flip ? -(int)(B.sx * 4u) : (int)(B.sx * 4u);
   for (int kb = 0; kb < D.n2; kb += FSG_WAVE) {
-    fsg_tap ck[4] = {none, none, none, none}, cbk[4] = {none, none, none, none};
-    const int k = min(kb + lane, D.n2 - 1);
-    if (D.field) ck[0] = D.tz[k];
-    if (E.bias) cbk[0] = E.bz[k];
-    if (live_row)
-      warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, 1>(D, E, m, sm, nf, i, j, kb + lane, ck, cbk, row, src_lin, out_lin,
-                                                  src_nn, out_nn);
+    const int kk = kb + lane;
+    const int k = min(kk, D.n2 - 1);
+    // NB: written as `if`, not `cond ? table[k] : none`: the ternary makes hipcc scalarise the 16-byte entry
+    // into eight branchy dword loads (+35 % kernel time, measured)
+    fsg_tap c = none, cb = none;
+    if (D.field) c = D.tz[k];
+    if (E.bias) cb = E.bz[k];
+    if (BUF) {
+      warp_emit_buf<LT, HAS_LIN, HAS_NN, FAST>(D, E, m, B, sm, nf, i, j, k, live_row && kk < D.n2, c, cb, row, out_lin,
+                                               out_nn);
+    } else if (live_row) {
+      const fsg_tap ck[4] = {c, none, none, none}, cbk[4] = {cb, none, none, none};
+      warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, 1>(D, E, m, sm, nf, i, j, kk, ck, cbk, row, src_lin, out_lin, src_nn,
+                                                  out_nn);
+    }
     __syncthreads();  // keep the 16 waves on the same z chunk: bounded L1 working set, shared misses
   }
 }
@@ -1032,8 +1136,16 @@ int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, f
     const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
     const dim3 grid((unsigned)ntiles), block(1024);
     hipStream_t st = fsg_stream(stream);
-#define FSG_LAUNCH_PATCH(L, N, F) \
-  hipLaunchKernelGGL((warp_patch_kernel<LT, L, N, F>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+    const bool buf = (g_tuning_flags & FSG_TUNE_BUFFER_LOADS) != 0;
+#define FSG_LAUNCH_PATCH(L, N, F)                                                                                      \
+  do {                                                                                                                 \
+    if (buf)                                                                                                           \
+      hipLaunchKernelGGL((warp_patch_kernel<LT, L, N, F, true>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, \
+                         out_nn, E);                                                                                   \
+    else                                                                                                               \
+      hipLaunchKernelGGL((warp_patch_kernel<LT, L, N, F, false>), grid, block, 0, st, D, mm6, src_lin, out_lin,        \
+                         src_nn, out_nn, E);                                                                           \
+  } while (0)
     if (src_lin && src_nn) { if (fast) FSG_LAUNCH_PATCH(true, true, true); else FSG_LAUNCH_PATCH(true, true, false); }
     else if (src_lin)      { if (fast) FSG_LAUNCH_PATCH(true, false, true); else FSG_LAUNCH_PATCH(true, false, false); }
     else                   { FSG_LAUNCH_PATCH(false, true, true); }

@@ -17,8 +17,11 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--m", type=int, default=171, help="low-res size for the resample kernels")
 ap.add_argument("--rot", type=float, default=12.0, help="rotation (degrees) about each axis")
+ap.add_argument("--tune", type=int, default=0, help="fsg_set_tuning flags")
 args = ap.parse_args()
 dev = "cuda:0"
+from fetalsyngen_amd import _lib
+_lib.load().fsg_set_tuning(args.tune)
 n = args.size
 shape = (n, n, n)
 N = n ** 3
