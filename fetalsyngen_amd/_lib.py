@@ -103,6 +103,7 @@ SIGNATURES = {
     "fsg_gmm_sample_u8": [P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_gmm_sample_i64": [P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_gmm_sample_u8x4": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, P],
+    "fsg_gmm_sample_u8x4_mm": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, P, I, I, P],
     "fsg_label_stats_u8": [P, P, SZ, I, P, P, P, P],
     "fsg_zoom3d_f32": [P, I, I, I, I, P, P, P, P, I, I, I, P],
     "fsg_resample_noise_f32": [P, I, I, I, P, P, P, P, I, I, I, I, P, U64, U64, F, P],

@@ -1294,7 +1294,9 @@ int fsg_coords_floormin_f32(const fsg_deform* d, int32_t* mm3, void* stream) {
   hipLaunchKernelGGL(coords_faces_min_kernel, dim3(g1), dim3(256), 0, st, D, mm3);
   const int rows = D.n0 * D.n1;
   if ((D.field ? 3 * D.f2 : 0) <= ROWCAP) {
-    int grid = (rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048;
+    // 512 workgroups: in the usual case every one of them exits on its first instruction, and fewer of them
+    // exit sooner; the rare full pass runs at a quarter of the parallelism, which is fine
+    int grid = (rows + 7) / 8 < 512 ? (rows + 7) / 8 : 512;
     const int rpb = (rows + grid - 1) / grid;
     grid = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(coords_minmax_rows_kernel<true>, dim3(grid), dim3(256), 0, st, D, mm3, rpb);

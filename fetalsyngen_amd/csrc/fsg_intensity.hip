@@ -58,12 +58,16 @@ __global__ __launch_bounds__(256) void gmm_x4_kernel(const uint8_t* __restrict__
                                                      size_t n, const float* __restrict__ mus,
                                                      const float* __restrict__ sigmas, int ntab,
                                                      const float* __restrict__ noise, uint64_t seed,
-                                                     uint64_t stream_id, float* __restrict__ out) {
+                                                     uint64_t stream_id, float* __restrict__ out,
+                                                     int32_t* __restrict__ mm, int nmin, int nmax) {
   __shared__ float s_mu[256], s_sg[256];
   for (int t = threadIdx.x; t < 256; t += blockDim.x) {
     s_mu[t] = t < ntab ? mus[t] : 0.f;
     s_sg[t] = t < ntab ? sigmas[t] : 0.f;
   }
+  // first kernel of a sample: also resets the sample's min/max keys (saves a launch)
+  if (mm && blockIdx.x == 0 && (int)threadIdx.x < nmin + nmax)
+    mm[threadIdx.x] = (int)threadIdx.x < nmin ? fsg_f2key(INFINITY) : fsg_f2key(-INFINITY);
   __syncthreads();
   const size_t nblk = (n + 3) >> 2;
   for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nblk; g += (size_t)gridDim.x * blockDim.x) {
@@ -229,12 +233,20 @@ int fsg_gmm_sample_u8(const uint8_t* labels, size_t n, const float* mus, const f
 int fsg_gmm_sample_u8x4(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
                         const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
                         uint64_t stream_id, float* out, void* stream) {
-  if (n == 0) return 0;
+  return fsg_gmm_sample_u8x4_mm(l0, l1, l2, l3, n, mus, sigmas, ntab, noise, seed, stream_id, out, nullptr, 0, 0,
+                                stream);
+}
+
+int fsg_gmm_sample_u8x4_mm(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                           const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                           uint64_t stream_id, float* out, int32_t* mm, int nmin, int nmax, void* stream) {
+  if (mm && (nmin < 0 || nmax < 0 || nmin + nmax > 64)) return FSG_E_BADARG;
+  if (n == 0) return mm ? fsg_minmax_init(mm, nmin, nmax, stream) : 0;
   if (!l0 || !mus || !sigmas || !out || ntab <= 0 || ntab > 256) return FSG_E_BADARG;
   const uintptr_t al = (uintptr_t)l0 | (uintptr_t)l1 | (uintptr_t)l2 | (uintptr_t)l3;
   if ((al & 3) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
   hipLaunchKernelGGL(gmm_x4_kernel, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, fsg_stream(stream), l0, l1, l2, l3,
-                     n, mus, sigmas, ntab, noise, seed, stream_id, out);
+                     n, mus, sigmas, ntab, noise, seed, stream_id, out, mm, nmin, nmax);
   FSG_RETURN_LAUNCH();
 }
 

@@ -22,12 +22,11 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   if (n > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
 
-  // every min/max key of the sample in one launch: [min x,y,z | zoom min] [zoom max | 3 unused]
-  FSG_TRY(fsg_minmax_init(p->mm8, 4, 4, stream));
-
-  // K1: GMM draw -> ws0
-  FSG_TRY(fsg_gmm_sample_u8x4(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
-                              p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, stream));
+  // K1: GMM draw -> ws0; the same launch resets every min/max key of the sample:
+  // [min x,y,z | zoom min] [zoom max | 3 unused]
+  FSG_TRY(fsg_gmm_sample_u8x4_mm(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n,
+                                 p->mus, p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0,
+                                 p->mm8, 4, 4, stream));
   float* cur = p->ws0;
   float* other = p->ws1;
   const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;

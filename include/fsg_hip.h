@@ -95,6 +95,11 @@ int fsg_gmm_sample_i64(const int64_t* labels, size_t n, const float* mus, const 
 int fsg_gmm_sample_u8x4(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
                         const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
                         uint64_t stream_id, float* out, void* stream);
+/* Same, and additionally resets `nmin` + `nmax` min/max keys at `mm` (as fsg_minmax_init would): the GMM draw is
+ * the first kernel of a sample, folding the reset into it saves a launch.  mm may be NULL. */
+int fsg_gmm_sample_u8x4_mm(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                           const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                           uint64_t stream_id, float* out, int32_t* mm, int nmin, int nmax, void* stream);
 
 /* Per-label count / sum / sum of squares of `values` (wave-level reductions); accumulates into the
  * caller-zeroed outputs.  Used to validate device-RNG GMM draws against mus/sigmas. */
