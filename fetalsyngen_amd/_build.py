@@ -9,7 +9,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libfsg_hip.so"
-SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip", "fsg_pipeline.cpp"]
+SOURCES = ["fsg_deform.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_reduce.hip", "fsg_slice_acq.hip", "fsg_artifacts.hip",
+           "fsg_pipeline.cpp"]
 EXTRA = os.environ.get("FSG_EXTRA_FLAGS", "").split()
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -40,10 +41,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         o = build_dir / (s + ".o")
         lang = ["-x", "hip"] if s.endswith(".cpp") else []
         cmd = [cc, *FLAGS, *EXTRA, *lang, "-c", str(CSRC / s), "-o", str(o)]
+        objs.append(str(o))
+        deps = [CSRC / s, CSRC / "fsg_common.h", PKG.parent / "include" / "fsg_hip.h", Path(__file__)]
+        if not force and not EXTRA and o.exists() and all(d.stat().st_mtime < o.stat().st_mtime for d in deps):
+            continue  # object is newer than its source and the shared headers
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-        objs.append(str(o))
     tmp = LIB.with_suffix(".so.tmp")
     subprocess.run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", str(tmp)], check=True)
     os.replace(tmp, LIB)

@@ -125,6 +125,15 @@ SIGNATURES = {
     "fsg_add_noise_f32": [P, SZ, P, U64, U64, F, P, P],
     "fsg_reduce_minmax_f32": [P, SZ, P, P],
     "fsg_scale_f32": [P, SZ, P, I, P, P],
+    "fsg_slice_acq_forward_f32": [P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, I, P],
+    "fsg_slice_acq_adjoint_f32": [P, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "fsg_equalize_f32": [P, P, P, F, SZ, P],
+    "fsg_mog3d_f32": [P, P, I, I, I, I, P, P, P],
+    "fsg_perlin_fractal_f32": [P, P, P, P, I, I, I, I, P, P, P],
+    "fsg_blend_f32": [P, P, P, SZ, I, P, F, P, I, P, P, F, P, P, P],
+    "fsg_slice_noise_f32": [P, SZ, F, F, P, P, U64, U64, P],
+    "fsg_slice_void_f32": [P, I, I, P, P, I, P, P, P],
+    "fsg_slice_sums_f32": [P, I, SZ, P, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],

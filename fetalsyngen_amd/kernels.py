@@ -443,3 +443,84 @@ def scale(x, mm, mode: int) -> torch.Tensor:
     out = torch.empty_like(_f32(x))
     _lib.check(_lib.load().fsg_scale_f32(_p(x), x.numel(), _p(mm), mode, _p(out), _stream(x)), "fsg_scale_f32")
     return out
+
+
+# ---- SR-artifact slice-stack simulation (fsg_slice_acq.hip) -------------------------------------------
+SA_MODES = {"linear": 0, "nearest_psf": 1, "torch": 2}
+
+
+def _sa_mode(semantics: str, interp_psf: bool) -> int:
+    if semantics == "torch":
+        return SA_MODES["torch"]
+    if semantics != "cuda":
+        raise ValueError(f"semantics must be 'cuda' or 'torch', got {semantics!r}")
+    return SA_MODES["nearest_psf"] if interp_psf else SA_MODES["linear"]
+
+
+def _sa_mask(m, shape, name):
+    if m is None or m.numel() == 0:
+        return None
+    _need_gpu(m)
+    if m.dtype not in (torch.bool, torch.uint8):
+        raise TypeError(f"{name} must be bool/uint8, got {m.dtype}")
+    if tuple(m.shape[-len(shape):]) != tuple(shape) or m.numel() != int(np.prod(shape)):
+        raise ValueError(f"{name} shape {tuple(m.shape)} does not match {tuple(shape)}")
+    return m
+
+
+def _sa_common(transforms, psf):
+    _need_gpu(transforms, psf)
+    _f32(transforms, "transforms"), _f32(psf, "psf")
+    if transforms.dim() != 3 or tuple(transforms.shape[1:]) != (3, 4):
+        raise ValueError(f"transforms must be (n,3,4), got {tuple(transforms.shape)}")
+    if psf.dim() != 3:
+        raise ValueError(f"psf must be 3-D, got {tuple(psf.shape)}")
+    return int(transforms.shape[0]), tuple(int(v) for v in psf.shape)
+
+
+def slice_acq_forward(transforms, vol, vol_mask, slices_mask, psf, slice_shape, res_slice, need_weight=False,
+                      interp_psf=False, semantics="cuda"):
+    """(n,3,4) transforms x (D,H,W) volume -> (n,h,w) slices [, weights]  (fsg_slice_acq_forward_f32)."""
+    n, (pd, ph, pw) = _sa_common(transforms, psf)
+    _need_gpu(vol)
+    D, H, W = _dims3(_f32(vol, "vol"))
+    h, w = int(slice_shape[0]), int(slice_shape[1])
+    vm, sm = _sa_mask(vol_mask, (D, H, W), "vol_mask"), _sa_mask(slices_mask, (n, h, w), "slices_mask")
+    out = torch.empty((n, h, w), dtype=F32, device=vol.device)
+    wgt = torch.empty_like(out) if need_weight else None
+    rc = _lib.load().fsg_slice_acq_forward_f32(_p(transforms), _p(vol), _p(vm), _p(psf), pd, ph, pw, _p(sm), _p(out),
+                                               _p(wgt), D, H, W, n, h, w, float(res_slice),
+                                               _sa_mode(semantics, interp_psf), _stream(vol))
+    _lib.check(rc, "fsg_slice_acq_forward_f32")
+    return (out, wgt) if need_weight else out
+
+
+def slice_acq_adjoint(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf=False,
+                      equalize=False, semantics="cuda", return_weight=False, slice_ids=None):
+    """(n,h,w) slices -> (D,H,W) volume  (fsg_slice_acq_adjoint_f32 + fsg_equalize_f32).
+    slice_ids (int32, device, len(transforms)): use slices[slice_ids[z]] for transform z (subset without a copy)."""
+    n, (pd, ph, pw) = _sa_common(transforms, psf)
+    _need_gpu(slices, slice_ids)
+    _f32(slices, "slices")
+    ns = int(slices.shape[0])
+    if slices.dim() != 3 or (slice_ids is None and ns != n):
+        raise ValueError(f"slices must be (n,h,w) with n={n}, got {tuple(slices.shape)}")
+    if slice_ids is not None:
+        if slice_ids.dtype != torch.int32 or slice_ids.numel() != n:
+            raise ValueError("slice_ids must be int32 with one entry per transform")
+    h, w = int(slices.shape[1]), int(slices.shape[2])
+    D, H, W = (int(v) for v in vol_shape)
+    vm, sm = _sa_mask(vol_mask, (D, H, W), "vol_mask"), _sa_mask(slices_mask, (ns, h, w), "slices_mask")
+    vol = torch.empty((D, H, W), dtype=F32, device=slices.device)
+    wgt = torch.empty_like(vol) if (equalize or return_weight) else None
+    mode = _sa_mode(semantics, interp_psf)
+    lib, st = _lib.load(), _stream(slices)
+    rc = lib.fsg_slice_acq_adjoint_f32(_p(transforms), _p(psf), pd, ph, pw, _p(slices), _p(sm), _p(slice_ids), _p(vm),
+                                       _p(vol), _p(wgt), D, H, W, n, h, w, float(res_slice), mode, st)
+    _lib.check(rc, "fsg_slice_acq_adjoint_f32")
+    torch_sem = mode == SA_MODES["torch"]
+    if equalize or (torch_sem and vm is not None):
+        rc = lib.fsg_equalize_f32(_p(vol), _p(wgt if equalize else None), _p(vm if torch_sem else None),
+                                  1e-2 if torch_sem else 0.0, vol.numel(), st)
+        _lib.check(rc, "fsg_equalize_f32")
+    return (vol, wgt) if return_weight else vol

@@ -213,6 +213,79 @@ int fsg_scale_f32(const float* x, size_t n, const int32_t* mm, int mode, float* 
 /* Decode ordered keys on the host side helper (pure function, no GPU). */
 float fsg_key_to_float(int32_t key);
 
+/* ---- SR-artifact slice-stack simulation ------------------------------------------------- */
+/* Slice acquisition and its adjoint: the two operators of generator/artifacts/simulate_reco.py
+ * (Scanner.scan :386-407 calls the forward, PSFreconstruction :38-54 the adjoint).  They replace the
+ * reference's own CUDA extension, generator/artifacts/svort/slice_acquisition/slice_acq_cuda.cpp:22-160
+ * (`forward`, `adjoint_forward`) and its kernels slice_acq_cuda_kernel.cu:17-171, :472-693.
+ *   transforms (n,3,4) fp32 row-major [R|t], "translation first": p = R (pixel + t)
+ *   vol (D,H,W) fp32, x fastest; psf (pd,ph,pw) fp32; slices (n,h,w) fp32
+ *   vol_mask (D,H,W) / slices_mask (n,h,w): one byte per element (torch.bool), or NULL
+ * mode selects which of the reference's two arithmetics is followed:
+ *   FSG_SA_LINEAR      CUDA kernel, interp_psf=false: trilinear volume sample per PSF tap (:110-161, :607-666)
+ *   FSG_SA_NEAREST_PSF CUDA kernel, interp_psf=true : nearest voxel (round half away from zero), PSF
+ *                      re-interpolated at that voxel (:71-109, :572-605)
+ *   FSG_SA_TORCH       the CPU fallback slice_acq.py:266-546 (nearest voxel by round-half-even, strict inside
+ *                      test, raw PSF taps > 0, normalisation where weight > 1e-2, no per-pixel weight in the adjoint)
+ * PSF limits: each extent <= 64, pd*ph*pw <= 4096 (it is staged in LDS), else FSG_E_TOOBIG. */
+#define FSG_SA_LINEAR 0
+#define FSG_SA_NEAREST_PSF 1
+#define FSG_SA_TORCH 2
+/* slices = A(vol) / weight where weight > 0 (CUDA modes; > 1e-2 in FSG_SA_TORCH), 0 elsewhere and outside
+ * slices_mask; slices_weight (may be NULL) receives the weights.  Every element of both outputs is written. */
+int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const uint8_t* vol_mask, const float* psf, int pd,
+                              int ph, int pw, const uint8_t* slices_mask, float* slices, float* slices_weight, int D, int H,
+                              int W, int n, int h, int w, float res_slice, int mode, void* stream);
+/* vol = A^T(slices), vol_weight = A^T(1) (may be NULL); both are zeroed by the call, then accumulated with
+ * fp32 atomics (as the reference does: the summation order is not deterministic).  CUDA modes skip pixels whose
+ * PSF weight inside the volume is < 0.5 and divide each contribution by that weight (:560, :600, :616).
+ * slice_ids (DEVICE, n x int32, may be NULL): transform z of the launch applies to slices[slice_ids[z]] (and that
+ * row of slices_mask) -- the reconstruction keeps a random subset of the slices (simulate_reco.py:768-769)
+ * without copying them.
+ * Equalisation is a separate launch (fsg_equalize_f32), as in the reference (:1062-1074). */
+int fsg_slice_acq_adjoint_f32(const float* transforms, const float* psf, int pd, int ph, int pw, const float* slices,
+                              const uint8_t* slices_mask, const int32_t* slice_ids, const uint8_t* vol_mask, float* vol,
+                              float* vol_weight, int D, int H, int W, int n, int h, int w, float res_slice, int mode,
+                              void* stream);
+/* vol[i] /= vol_weight[i] where vol_weight[i] > threshold (0 for the CUDA kernel :681-691, 1e-2 for the
+ * fallback slice_acq.py:542-543); then vol[i] *= vol_mask[i] if vol_mask (fallback :544-545).  Either of
+ * vol_weight / vol_mask may be NULL, not both. */
+int fsg_equalize_f32(float* vol, const float* vol_weight, const uint8_t* vol_mask, float threshold, size_t n, void* stream);
+
+/* ---- SR-artifact volumetric helpers, fsg_artifacts.hip ------------------------------------ */
+/* out = clamp(sum_g exp(-(((x-c0)/s0)^2 + ((y-c1)/s1)^2 + ((z-c2)/s2)^2) / 2), 0, 1) over a (D,H,W) grid with
+ * x the LAST axis -- generator/artifacts/utils.py:125-160 `mog_3d_tensor`, including its convention that a
+ * centre is unpacked as (x0,y0,z0) (callers pass first-axis indices first: the reference's own transposition).
+ * centers, sigmas: DEVICE (k,3) fp32.  tables: caller-owned workspace of k*3*max(D,H,W) floats. */
+int fsg_mog3d_f32(const float* centers, const float* sigmas, int k, int D, int H, int W, float* tables, float* out,
+                  void* stream);
+/* Raw fractal Perlin noise sum_q amps[q] * perlin_q (generator/artifacts/utils.py:224-384) on an (n0,n1,n2) grid and
+ * its min / max (ordered keys, mm[0], mm[1]; caller initialises with fsg_minmax_init(mm,1,1)).  Per octave q:
+ * grads[q] DEVICE (r0+1,r1+1,r2+1,3) unit gradients (tileable wrap already applied), lins[q] DEVICE
+ * linspace(0,r_a,n_a) for the three axes back to back, res[3q..3q+2] = (r0,r1,r2).  grads/lins/res/amps: HOST arrays. */
+int fsg_perlin_fractal_f32(const float* const* grads, const float* const* lins, const int32_t* res, const float* amps,
+                           int noct, int n0, int n1, int n2, float* out, int32_t* mm, void* stream);
+/* out = (1 - w) a + w b, the spatially weighted merge of simulate_reco.py:704, augmentation/artifacts.py:125, :337.
+ *   w_mode 0: w is the weight volume; 1: w is raw Perlin noise, normalised on the fly as
+ *             clamp((w + increase - min) / (max - min), 0, 1) with w_mm from fsg_perlin_fractal_f32 (utils.py:386-387);
+ *   seg != NULL: w *= (seg > 0)                                              (artifacts.py:336-337);
+ *   b_mode 1: b is the multi-scale noise field, b' = clamp(a + std * b / max|b|, 0, 2 max a) with b_mm / a_mm the
+ *             min/max keys of b and a                                        (artifacts.py:322-327).
+ * out may be NULL (then only w_out, the weight actually used, is written); w_out may be NULL. */
+int fsg_blend_f32(const float* a, const float* b, const float* w, size_t n, int w_mode, const int32_t* w_mm, float increase,
+                  const float* seg, int b_mode, const int32_t* b_mm, const int32_t* a_mm, float std, float* out,
+                  float* w_out, void* stream);
+/* Scanner.add_noise (simulate_reco.py:236-256), in place: s = sqrt((s + sigma z1)^2 + (sigma z2)^2) where s > threshold.
+ * noise1/noise2 dense fields (host-tape mode) or both NULL: Philox(seed, stream_id), two normals per pixel. */
+int fsg_slice_noise_f32(float* slices, size_t n, float threshold, float sigma, const float* noise1, const float* noise2,
+                        uint64_t seed, uint64_t stream_id, void* stream);
+/* Scanner.signal_void (simulate_reco.py:258-298), in place on the nvoid slices slice_ids[t]:
+ * s *= 1 - A exp(sx x'^2 + sy y'^2); params (nvoid,7) = {yc, xc, cos, sin, A, sx, sy}; ylin (h), xlin (w). */
+int fsg_slice_void_f32(float* slices, int h, int w, const int32_t* slice_ids, const float* params, int nvoid,
+                       const float* ylin, const float* xlin, void* stream);
+/* sums[i] = sum of slice i (simulate_reco.py:409), deterministic. */
+int fsg_slice_sums_f32(const float* slices, int n, size_t hw, float* sums, void* stream);
+
 /* ---- whole-sample launch sequence -------------------------------------------------------------------------- */
 /* One call = the fused kernel sequence of FetalSynthGen.sample (generator/model.py:231-276) for the
  * seeds-based path: GMM draw -> [rows, margins, warp(+gamma+bias, labels)] -> [blur x,y,z, resample+noise,

@@ -522,7 +522,57 @@ def g_config1(R, ref):
     save("config1_sta21_128", **res)
 
 
+def _rigid_transforms(rng, n, max_rot=0.5, max_t=3.0):
+    """n random 3x4 [R|t] (rotation about a random axis, translation), float32."""
+    out = np.zeros((n, 3, 4), dtype=np.float32)
+    for i in range(n):
+        ax = rng.standard_normal(3)
+        ax /= np.linalg.norm(ax)
+        th = rng.uniform(-max_rot, max_rot)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        out[i, :, :3] = R
+        out[i, :, 3] = rng.uniform(-max_t, max_t, 3)
+    return out
+
+
+def g_slice_acq(R):
+    """SVoRT slice acquisition / adjoint: the reference's torch (CPU) fallback
+    (svort/slice_acquisition/slice_acq.py:266-546); its CUDA kernels cannot run here."""
+    import importlib
+
+    # (the package's __init__ rebinds the name `slice_acquisition` to a function, so go through sys.modules)
+    SA = importlib.import_module("fetalsyngen.generator.artifacts.svort.slice_acquisition.slice_acq")
+    get_PSF = importlib.import_module("fetalsyngen.generator.artifacts.svort.data.utils").get_PSF
+
+    rng = np.random.default_rng(91)
+    out = {}
+    psfs = {"aniso": get_PSF(res_ratio=(1, 1, 3)), "iso": get_PSF(res_ratio=(1.2, 1.2, 1.2)), "delta": get_PSF(0)}
+    for k, v in psfs.items():
+        out[f"psf_{k}"] = v.numpy()
+    vol = rng.random((1, 1, 20, 24, 28), dtype=np.float32) * 100
+    tr = _rigid_transforms(rng, 5)
+    vmask = rng.random(vol.shape) > 0.2
+    smask = rng.random((5, 1, 14, 18)) > 0.3
+    out["vol"], out["transforms"], out["vol_mask"], out["slices_mask"] = vol[0, 0], tr, vmask[0, 0], smask[:, 0]
+    T = torch.from_numpy
+    for pk in ("aniso", "iso"):
+        for mk, (vm, sm) in {"nomask": (None, None), "masks": (T(vmask), T(smask))}.items():
+            s, w = SA.slice_acquisition_torch(T(tr), T(vol), vm, sm, psfs[pk], (14, 18), 1.3, True)
+            out[f"fwd_{pk}_{mk}"] = s.numpy()[:, 0]
+            out[f"fwdw_{pk}_{mk}"] = w.numpy()[:, 0]
+            for eq in (False, True):
+                v = SA.slice_acquisition_adjoint_torch(T(tr), psfs[pk], s, sm, vm, (20, 24, 28), 1.3, eq)
+                out[f"adj_{pk}_{mk}_eq{int(eq)}"] = v.numpy()[0, 0]
+    # 1x1x1 PSF without weights takes the grid_sample path (slice_acq.py:381-384, :445-480)
+    s = SA.slice_acquisition_torch(T(tr), T(vol), None, None, psfs["delta"], (14, 18), 1.3, False)
+    out["fwd_delta_nomask"] = s.numpy()[:, 0]
+    out["res_slice"] = np.float32(1.3)
+    save("slice_acq", **out)
+
+
 ALL = {
+    "slice_acq": g_slice_acq,
     "affine": g_affine, "gauss": g_gauss, "blur": g_blur, "zoom": g_zoom, "interp": g_interp,
     "deform_image": g_deform_image, "gmm": g_gmm, "stages": g_stages, "e2e": g_e2e,
 }
