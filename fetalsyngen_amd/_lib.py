@@ -134,6 +134,12 @@ SIGNATURES = {
     "fsg_slice_noise_f32": [P, SZ, F, F, P, P, U64, U64, P],
     "fsg_slice_void_f32": [P, I, I, P, P, I, P, P, P],
     "fsg_slice_sums_f32": [P, I, SZ, P, P],
+    "fsg_nonzero_count_f32": [P, SZ, I, F, P, P],
+    "fsg_nonzero_count_u8": [P, SZ, I, F, P, P],
+    "fsg_nonzero_select_f32": [P, SZ, I, F, P, P, I, P, P],
+    "fsg_nonzero_select_u8": [P, SZ, I, F, P, P, I, P, P],
+    "fsg_compact_f32": [P, P, SZ, I, F, P, P, P],
+    "fsg_ewise_f32": [P, P, SZ, I, F, P, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],

@@ -15,6 +15,11 @@ _MODULES = [
     "generator.deformation.affine_nonrigid",
     "generator.augmentation",
     "generator.augmentation.synthseg",
+    "generator.augmentation.artifacts",
+    "generator.artifacts",
+    "generator.artifacts.utils",
+    "generator.artifacts.simulate_reco",
+    "generator.artifacts.svort",
     "data",
     "data.datasets",
     "utils",

@@ -215,6 +215,88 @@ __global__ __launch_bounds__(1024) void slice_sums_kernel(const float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
 }
 
+
+// ---- k-th set voxel (torch.where(mask)[...][randperm] of the reference, without materialising the index lists) --
+constexpr int NZ_BLOCK = 4096;  // voxels per count bucket
+
+template <typename T>
+__device__ __forceinline__ bool nz_pred(T v, int mode, float value) {
+  const float f = (float)v;
+  return mode == 0 ? f > value : (mode == 1 ? f == value : f != value);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nonzero_count_kernel(const T* __restrict__ v, size_t n, int mode, float value,
+                                                            int32_t* __restrict__ counts) {
+  const size_t base = (size_t)blockIdx.x * NZ_BLOCK;
+  int c = 0;
+  for (int e = threadIdx.x; e < NZ_BLOCK; e += 256)
+    if (base + e < n && nz_pred(v[base + e], mode, value)) ++c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, FSG_WAVE);
+  __shared__ int red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one wave per request: flat index of the rank[q]-th set voxel (raster order) of bucket blk[q]
+template <typename T>
+__global__ __launch_bounds__(64) void nonzero_select_kernel(const T* __restrict__ v, size_t n, int mode, float value,
+                                                            const int32_t* __restrict__ blk, const int32_t* __restrict__ rank,
+                                                            long long* __restrict__ out) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const size_t base = (size_t)blk[q] * NZ_BLOCK;
+  int r = rank[q];
+  for (int it = 0; it < NZ_BLOCK / 64; ++it) {
+    const size_t e = base + (size_t)it * 64 + lane;
+    const bool p = e < n && nz_pred(v[e], mode, value);
+    const unsigned long long b = __ballot(p);
+    const int cnt = __popcll(b);
+    if (r < cnt) {
+      const int before = __popcll(b & ((1ull << lane) - 1ull));
+      if (p && before == r) out[q] = (long long)e;
+      return;
+    }
+    r -= cnt;
+  }
+  if (lane == 0) out[q] = -1;
+}
+
+
+// values[e] for the voxels of bucket b satisfying the predicate, written in raster order from offsets[b]
+__global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ values, const float* __restrict__ pv, size_t n,
+                                                     int mode, float value, const long long* __restrict__ offsets,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * NZ_BLOCK;
+  long long o = offsets[blockIdx.x];
+  for (int it = 0; it < NZ_BLOCK / 64; ++it) {
+    const size_t e = base + (size_t)it * 64 + lane;
+    const bool p = e < n && nz_pred(pv[e], mode, value);
+    const unsigned long long b = __ballot(p);
+    if (p) out[o + __popcll(b & ((1ull << lane) - 1ull))] = values[e];
+    o += __popcll(b);
+  }
+}
+
+// small element-wise helpers: 0: a + b, 1: a > value, 2: a == value, 3: a * b, 4: a * (b > value)
+__global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int op,
+                                                    float value, float* __restrict__ out) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float x = a[e];
+    float r;
+    switch (op) {
+      case 0: r = x + b[e]; break;
+      case 1: r = x > value ? 1.f : 0.f; break;
+      case 2: r = x == value ? 1.f : 0.f; break;
+      case 3: r = x * b[e]; break;
+      default: r = x * (b[e] > value ? 1.f : 0.f); break;
+    }
+    out[e] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -290,6 +372,50 @@ int fsg_slice_void_f32(float* slices, int h, int w, const int32_t* slice_ids, co
 int fsg_slice_sums_f32(const float* slices, int n, size_t hw, float* sums, void* stream) {
   if (!slices || !sums || n <= 0 || hw == 0) return FSG_E_BADARG;
   hipLaunchKernelGGL(slice_sums_kernel, dim3((unsigned)n), dim3(1024), 0, fsg_stream(stream), slices, hw, sums);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_nonzero_count_f32(const float* v, size_t n, int mode, float value, int32_t* counts, void* stream) {
+  if (!v || !counts || n == 0 || mode < 0 || mode > 2) return FSG_E_BADARG;
+  hipLaunchKernelGGL(nonzero_count_kernel<float>, dim3((unsigned)((n + NZ_BLOCK - 1) / NZ_BLOCK)), dim3(256), 0,
+                     fsg_stream(stream), v, n, mode, value, counts);
+  FSG_RETURN_LAUNCH();
+}
+int fsg_nonzero_count_u8(const uint8_t* v, size_t n, int mode, float value, int32_t* counts, void* stream) {
+  if (!v || !counts || n == 0 || mode < 0 || mode > 2) return FSG_E_BADARG;
+  hipLaunchKernelGGL(nonzero_count_kernel<uint8_t>, dim3((unsigned)((n + NZ_BLOCK - 1) / NZ_BLOCK)), dim3(256), 0,
+                     fsg_stream(stream), v, n, mode, value, counts);
+  FSG_RETURN_LAUNCH();
+}
+int fsg_nonzero_select_f32(const float* v, size_t n, int mode, float value, const int32_t* bucket, const int32_t* rank,
+                           int nreq, long long* out, void* stream) {
+  if (!v || !bucket || !rank || !out || n == 0 || nreq <= 0 || mode < 0 || mode > 2) return FSG_E_BADARG;
+  hipLaunchKernelGGL(nonzero_select_kernel<float>, dim3((unsigned)nreq), dim3(64), 0, fsg_stream(stream), v, n, mode, value,
+                     bucket, rank, out);
+  FSG_RETURN_LAUNCH();
+}
+int fsg_nonzero_select_u8(const uint8_t* v, size_t n, int mode, float value, const int32_t* bucket, const int32_t* rank,
+                          int nreq, long long* out, void* stream) {
+  if (!v || !bucket || !rank || !out || n == 0 || nreq <= 0 || mode < 0 || mode > 2) return FSG_E_BADARG;
+  hipLaunchKernelGGL(nonzero_select_kernel<uint8_t>, dim3((unsigned)nreq), dim3(64), 0, fsg_stream(stream), v, n, mode, value,
+                     bucket, rank, out);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_compact_f32(const float* values, const float* pred, size_t n, int mode, float value, const long long* offsets,
+                    float* out, void* stream) {
+  if (!values || !pred || !offsets || !out || n == 0 || mode < 0 || mode > 2) return FSG_E_BADARG;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((n + NZ_BLOCK - 1) / NZ_BLOCK)), dim3(64), 0, fsg_stream(stream), values,
+                     pred, n, mode, value, offsets, out);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_ewise_f32(const float* a, const float* b, size_t n, int op, float value, float* out, void* stream) {
+  if (!a || !out || n == 0 || op < 0 || op > 4) return FSG_E_BADARG;
+  if ((op == 0 || op >= 3) && !b) return FSG_E_BADARG;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), a, b, n, op, value, out);
   FSG_RETURN_LAUNCH();
 }
 

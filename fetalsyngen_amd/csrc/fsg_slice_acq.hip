@@ -279,7 +279,7 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_adjoint_kernel(SaParams P
 // strict inside test, round half to even, raw PSF value; one kernel serves forward and adjoint.
 // LDS: per-tap rotated offsets (3 floats) next to the PSF.
 // ---------------------------------------------------------------------------------------------------------
-template <bool ADJ>
+template <bool ADJ, bool GS = false>
 __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_torch_kernel(SaParams P, const float* __restrict__ vol_in,
                                                                     float* __restrict__ slices_io,
                                                                     float* __restrict__ weights_out,
@@ -325,6 +325,29 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_torch_kernel(SaParams P, 
   const float sz = T[8] * px + T[9] * py + T[10] * pz;
   const float lx = shx * 2, ly = shy * 2, lz = shz * 2;
   const int Sy = P.W, Sz = P.H * P.W;
+  if (GS) {
+    // 1x1x1 PSF without weights: slice_acquisition_no_psf_torch (slice_acq.py:445-480) = F.grid_sample(trilinear,
+    // zeros padding, align_corners=True) at R(pixel + T) / ((n-1)/2)
+    const float x = ((sx / shx + 1.f) / 2.f) * ((float)P.W - 1.f);
+    const float y = ((sy / shy + 1.f) / 2.f) * ((float)P.H - 1.f);
+    const float z = ((sz / shz + 1.f) / 2.f) * ((float)P.D - 1.f);
+    const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+    const float wx = x - xf, wy = y - yf, wz = z - zf;
+    const int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cx = x0 + (c & 1), cy = y0 + ((c >> 1) & 1), cz = z0 + (c >> 2);
+      if (cx < 0 || cy < 0 || cz < 0 || cx >= P.W || cy >= P.H || cz >= P.D) continue;
+      const float wgt = ((c & 1) ? wx : 1.f - wx) * (((c >> 1) & 1) ? wy : 1.f - wy) * ((c >> 2) ? wz : 1.f - wz);
+      const int iv = cz * Sz + cy * Sy + cx;
+      float v = vol_in[iv];
+      if (P.vmask) v = v * (float)P.vmask[iv];
+      acc += v * wgt;
+    }
+    slices_io[idx] = acc;
+    return;
+  }
   const float s = ADJ ? slices_io[idx] : 0.f;
   float val = 0.f, weight = 0.f;
   for (int e = 0; e < np; ++e) {
@@ -394,8 +417,12 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
   const dim3 grid = sa_grid(P), block(SA_TILE, SA_TILE);
   hipStream_t st = fsg_stream(stream);
   if (mode == FSG_SA_TORCH) {
-    hipLaunchKernelGGL(sa_torch_kernel<false>, grid, block, lds, st, P, vol, slices, slices_weight, (float*)nullptr,
-                       (float*)nullptr);
+    if (pd * ph * pw == 1 && !slices_weight)
+      hipLaunchKernelGGL((sa_torch_kernel<false, true>), grid, block, lds, st, P, vol, slices, slices_weight, (float*)nullptr,
+                         (float*)nullptr);
+    else
+      hipLaunchKernelGGL((sa_torch_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight, (float*)nullptr,
+                         (float*)nullptr);
   } else if (mode == FSG_SA_LINEAR) {
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<false, true>), grid, block, lds, st, P, vol, slices, slices_weight);
     else hipLaunchKernelGGL((sa_forward_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight);
@@ -426,7 +453,7 @@ int fsg_slice_acq_adjoint_f32(const float* transforms, const float* psf, int pd,
   const dim3 grid = sa_grid(P), block(SA_TILE, SA_TILE);
   if (mode == FSG_SA_TORCH) {
     // the fallback multiplies by vol_mask at the very end (fsg_equalize_f32), not per contribution
-    hipLaunchKernelGGL(sa_torch_kernel<true>, grid, block, lds, st, P, (const float*)nullptr, const_cast<float*>(slices),
+    hipLaunchKernelGGL((sa_torch_kernel<true, false>), grid, block, lds, st, P, (const float*)nullptr, const_cast<float*>(slices),
                        (float*)nullptr, vol, vol_weight);
   } else if (mode == FSG_SA_LINEAR) {
     if (vol_mask) hipLaunchKernelGGL((sa_adjoint_kernel<false, true>), grid, block, lds, st, P, slices, vol, vol_weight);

@@ -3,4 +3,4 @@ from .rigid import (RigidTransform, ax_update_resolution, axisangle2mat, init_ze
                     mat_update_resolution, random_angle, random_init_stack_transforms, reset_transform)
 from .scan import (get_PSF, get_trajectory, interleave_index, random_stack, resolution2sigma, sample_motion,  # noqa: F401
                    set_trajectory_bank, synthetic_trajectory_bank)
-from .slice_acquisition import slice_acquisition, slice_acquisition_adjoint  # noqa: F401
+from .slice_acq import get_semantics, set_semantics, slice_acquisition, slice_acquisition_adjoint  # noqa: F401

@@ -524,3 +524,234 @@ def slice_acq_adjoint(transforms, psf, slices, slices_mask, vol_mask, vol_shape,
                                   1e-2 if torch_sem else 0.0, vol.numel(), st)
         _lib.check(rc, "fsg_equalize_f32")
     return (vol, wgt) if return_weight else vol
+
+
+# ---- SR-artifact volumetric helpers (fsg_artifacts.hip) ----------------------------------------------------
+def _upload(host: torch.Tensor, device):
+    """Small host tensor -> device through a pinned staging copy (async on the current stream)."""
+    pin = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
+    pin.copy_(host)
+    return pin.to(device, non_blocking=True)
+
+
+def mog3d(shape, centers, sigmas, device) -> torch.Tensor:
+    """clamp(sum of k anisotropic Gaussians, 0, 1) on a (D,H,W) grid; centers/sigmas (k,3) in the (x0,y0,z0) order
+    `mog_3d_tensor` unpacks (x pairs with the LAST axis).  Host arrays or device tensors."""
+    D, H, W = (int(v) for v in shape)
+
+    def dev(a):
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.to(F32).contiguous()
+        return _upload(torch.as_tensor(np.asarray(a, dtype=np.float32)).reshape(-1, 3), device)
+
+    c, s = dev(centers), dev(sigmas)
+    k = int(c.shape[0])
+    if tuple(c.shape) != (k, 3) or tuple(s.shape) != (k, 3) or k == 0:
+        raise ValueError("centers and sigmas must be (k,3) with k >= 1")
+    out = torch.empty((D, H, W), dtype=F32, device=device)
+    tab = torch.empty(k * 3 * max(D, H, W), dtype=F32, device=device)
+    _lib.check(_lib.load().fsg_mog3d_f32(_p(c), _p(s), k, D, H, W, _p(tab), _p(out), _stream(out)), "fsg_mog3d_f32")
+    return out
+
+
+class PerlinPlan:
+    """Device-resident lattices of one fractal-noise draw: per octave the gradient lattice and the per-axis
+    linspace coordinates (built on the host in the reference's arithmetic, uploaded in one copy)."""
+
+    def __init__(self, shape, octaves, device):
+        # octaves: list of (grad (r0+1,r1+1,r2+1,3) fp32, [lin0, lin1, lin2] fp32, (r0,r1,r2), amplitude)
+        self.shape = tuple(int(v) for v in shape)
+        self.n = len(octaves)
+        if not 1 <= self.n <= 8:
+            raise ValueError("1..8 octaves")
+        flat, offs = [], []
+        pos = 0
+        for g, lins, r, _amp in octaves:
+            if tuple(g.shape) != (r[0] + 1, r[1] + 1, r[2] + 1, 3) or [len(v) for v in lins] != list(self.shape):
+                raise ValueError("perlin octave: lattice / axis table shapes do not match")
+            a = g.reshape(-1).to(F32)
+            b = torch.cat([v.to(F32) for v in lins])
+            offs.append((pos, pos + a.numel()))
+            flat += [a, b]
+            pos += a.numel() + b.numel()
+        self.buf = _upload(torch.cat(flat), device)
+        base = self.buf.data_ptr()
+        self.grads = (C.c_void_p * self.n)(*[base + 4 * o[0] for o in offs])
+        self.lins = (C.c_void_p * self.n)(*[base + 4 * o[1] for o in offs])
+        self.res = (C.c_int32 * (3 * self.n))(*[int(v) for o in octaves for v in o[2]])
+        self.amps = (C.c_float * self.n)(*[float(o[3]) for o in octaves])
+
+
+def perlin_fractal(plan: PerlinPlan, mm=None):
+    """Raw fractal noise volume + its (min,max) keys."""
+    dev = plan.buf.device
+    out = torch.empty(plan.shape, dtype=F32, device=dev)
+    if mm is None:
+        mm = new_minmax(dev, 1, 1)
+    n0, n1, n2 = plan.shape
+    rc = _lib.load().fsg_perlin_fractal_f32(plan.grads, plan.lins, plan.res, plan.amps, plan.n, n0, n1, n2, _p(out), _p(mm),
+                                            _stream(out))
+    _lib.check(rc, "fsg_perlin_fractal_f32")
+    return out, mm
+
+
+def blend(a, b, w, w_mm=None, increase=0.0, seg=None, noise_std=None, b_mm=None, a_mm=None, want_weight=False,
+          want_out=True):
+    """out = (1-w) a + w b (see fsg_blend_f32).  w_mm given: w is raw Perlin noise; noise_std given: b is the
+    multi-scale noise field of StructNoise (needs b_mm, a_mm)."""
+    _need_gpu(a, b, w, seg, w_mm, b_mm, a_mm)
+    n = int(w.numel())
+    for t_ in (a, b, seg):
+        if t_ is not None and (t_.numel() != n or t_.dtype != F32):
+            raise ValueError("blend operands must be float32 volumes of one size")
+    out = torch.empty_like(w) if want_out else None
+    w_out = torch.empty_like(w) if want_weight else None
+    rc = _lib.load().fsg_blend_f32(_p(a), _p(b), _p(w), n, 1 if w_mm is not None else 0, _p(w_mm), float(increase), _p(seg),
+                                   1 if noise_std is not None else 0, _p(b_mm), _p(a_mm),
+                                   float(noise_std if noise_std is not None else 0.0), _p(out), _p(w_out), _stream(w))
+    _lib.check(rc, "fsg_blend_f32")
+    return (out, w_out) if want_weight else out
+
+
+def slice_noise_(slices, threshold, sigma, noise1=None, noise2=None, seed=0, stream_id=0):
+    _need_gpu(slices, noise1, noise2)
+    _f32(slices, "slices")
+    rc = _lib.load().fsg_slice_noise_f32(_p(slices), slices.numel(), float(threshold), float(sigma), _p(noise1), _p(noise2),
+                                         int(seed), int(stream_id), _stream(slices))
+    _lib.check(rc, "fsg_slice_noise_f32")
+    return slices
+
+
+def slice_void_(slices, slice_ids, params, ylin, xlin):
+    """slices (n,h,w) modified in place on rows slice_ids (int32 device); params (nvoid,7) device fp32."""
+    _need_gpu(slices, slice_ids, params, ylin, xlin)
+    n, h, w = (int(v) for v in slices.shape)
+    nv = int(slice_ids.numel())
+    if slice_ids.dtype != torch.int32 or tuple(params.shape) != (nv, 7) or ylin.numel() != h or xlin.numel() != w:
+        raise ValueError("slice_void_: bad argument shapes")
+    rc = _lib.load().fsg_slice_void_f32(_p(slices), h, w, _p(slice_ids), _p(params), nv, _p(ylin), _p(xlin), _stream(slices))
+    _lib.check(rc, "fsg_slice_void_f32")
+    return slices
+
+
+def slice_sums(slices) -> torch.Tensor:
+    _need_gpu(slices)
+    _f32(slices, "slices")
+    n = int(slices.shape[0])
+    out = torch.empty(n, dtype=F32, device=slices.device)
+    rc = _lib.load().fsg_slice_sums_f32(_p(slices), n, slices.numel() // n, _p(out), _stream(slices))
+    _lib.check(rc, "fsg_slice_sums_f32")
+    return out
+
+
+NZ_BUCKET = 4096
+_NZ_MODES = {">": 0, "==": 1, "!=": 2}
+
+
+def nonzero_ranks(vol, op=">", value=0.0):
+    """Number of voxels of `vol` (float32 / bool / uint8, any shape) satisfying `vol op value`, and a function mapping
+    ranks (raster order among those voxels, int64 host tensor) to their coordinates, (k, vol.dim()) int64 on the host.
+    One host sync for the count, one per selection."""
+    _need_gpu(vol)
+    lib, st = _lib.load(), _stream(vol)
+    u8 = vol.dtype in (torch.bool, torch.uint8)
+    if not u8:
+        _f32(vol, "vol")
+    n, mode = int(vol.numel()), _NZ_MODES[op]
+    nb = (n + NZ_BUCKET - 1) // NZ_BUCKET
+    counts = torch.empty(nb, dtype=torch.int32, device=vol.device)
+    cnt_fn = lib.fsg_nonzero_count_u8 if u8 else lib.fsg_nonzero_count_f32
+    sel_fn = lib.fsg_nonzero_select_u8 if u8 else lib.fsg_nonzero_select_f32
+    _lib.check(cnt_fn(_p(vol), n, mode, float(value), _p(counts), st), "fsg_nonzero_count")
+    ends = np.cumsum(counts.cpu().numpy().astype(np.int64))
+    total = int(ends[-1]) if nb else 0
+    shape = tuple(vol.shape)
+
+    def select(ranks):
+        r = np.asarray(ranks, dtype=np.int64).reshape(-1)
+        if r.size == 0:
+            return torch.zeros((0, len(shape)), dtype=torch.int64)
+        if r.min() < 0 or r.max() >= total:
+            raise IndexError("rank out of range")
+        b = np.searchsorted(ends, r, side="right")
+        local = r - (ends[b] - counts_host[b])
+        req = torch.from_numpy(np.stack([b, local]).astype(np.int32))
+        d = _upload(req, vol.device)
+        out = torch.empty(r.size, dtype=torch.int64, device=vol.device)
+        _lib.check(sel_fn(_p(vol), n, mode, float(value), _p(d[0]), _p(d[1]), int(r.size), _p(out), _stream(vol)),
+                   "fsg_nonzero_select")
+        flat = out.cpu().numpy()
+        if (flat < 0).any():
+            raise RuntimeError("nonzero_select: volume changed between count and select")
+        return torch.from_numpy(np.stack(np.unravel_index(flat, shape), -1).astype(np.int64))
+
+    counts_host = np.diff(np.concatenate([[0], ends]))
+    return total, select
+
+
+def box_sum3d(v, k: int) -> torch.Tensor:
+    """Zero-padded k x k x k box sum (conv3d with a ones kernel, padding k//2): three passes of the blur kernels
+    with unit taps (exact for the small integers of a binary mask)."""
+    ones = np.ones(int(k), np.float32)
+    for axis in range(3):
+        v = blur_axis(v.contiguous(), axis, ones)
+    return v
+
+
+def compact_values(values, pred, op=">", value=0.0):
+    """values[pred op value] in raster order (device tensor) -- the boolean-mask gather, without the mask."""
+    _need_gpu(values, pred)
+    _f32(values, "values"), _f32(pred, "pred")
+    n, mode = int(pred.numel()), _NZ_MODES[op]
+    if values.numel() != n:
+        raise ValueError("values and pred must have one size")
+    lib = _lib.load()
+    nb = (n + NZ_BUCKET - 1) // NZ_BUCKET
+    counts = torch.empty(nb, dtype=torch.int32, device=pred.device)
+    _lib.check(lib.fsg_nonzero_count_f32(_p(pred), n, mode, float(value), _p(counts), _stream(pred)), "fsg_nonzero_count")
+    c = counts.cpu().numpy().astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(c)[:-1]]) if nb else np.zeros(0, np.int64)
+    total = int(c.sum())
+    out = torch.empty(total, dtype=F32, device=pred.device)
+    if total:
+        d = _upload(torch.from_numpy(offs.astype(np.int64)), pred.device)
+        _lib.check(lib.fsg_compact_f32(_p(values), _p(pred), n, mode, float(value), _p(d), _p(out), _stream(pred)),
+                   "fsg_compact_f32")
+    return out
+
+
+_EWISE = {"add": 0, "gt": 1, "eq": 2, "mul": 3, "mul_gt": 4}
+
+
+def _ewise(op, a, b=None, value=0.0):
+    _need_gpu(a, b)
+    _f32(a, "a")
+    if b is not None and (_f32(b, "b").numel() != a.numel()):
+        raise ValueError("operands must have one size")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().fsg_ewise_f32(_p(a), _p(b), a.numel(), _EWISE[op], float(value), _p(out), _stream(a)),
+               "fsg_ewise_f32")
+    return out
+
+
+def axpy(a, b):
+    """a + b."""
+    return _ewise("add", a, b)
+
+
+def threshold(a, value=0.0):
+    """(a > value) as float32 0/1."""
+    return _ewise("gt", a, None, value)
+
+
+def equals(a, value):
+    return _ewise("eq", a, None, value)
+
+
+def mul(a, b):
+    return _ewise("mul", a, b)
+
+
+def mask_mul(a, b, value=0.0):
+    """a * (b > value)."""
+    return _ewise("mul_gt", a, b, value)

@@ -226,7 +226,9 @@ float fsg_key_to_float(int32_t key);
  *   FSG_SA_NEAREST_PSF CUDA kernel, interp_psf=true : nearest voxel (round half away from zero), PSF
  *                      re-interpolated at that voxel (:71-109, :572-605)
  *   FSG_SA_TORCH       the CPU fallback slice_acq.py:266-546 (nearest voxel by round-half-even, strict inside
- *                      test, raw PSF taps > 0, normalisation where weight > 1e-2, no per-pixel weight in the adjoint)
+ *                      test, raw PSF taps > 0, normalisation where weight > 1e-2, no per-pixel weight in the adjoint);
+ *                      a 1x1x1 PSF without slices_weight takes the fallback's grid_sample route (slice_acq.py:381-384,
+ *                      :445-480: trilinear, zero padding, slices_mask applied) in the forward
  * PSF limits: each extent <= 64, pd*ph*pw <= 4096 (it is staged in LDS), else FSG_E_TOOBIG. */
 #define FSG_SA_LINEAR 0
 #define FSG_SA_NEAREST_PSF 1
@@ -285,6 +287,28 @@ int fsg_slice_void_f32(float* slices, int h, int w, const int32_t* slice_ids, co
                        const float* ylin, const float* xlin, void* stream);
 /* sums[i] = sum of slice i (simulate_reco.py:409), deterministic. */
 int fsg_slice_sums_f32(const float* slices, int n, size_t hw, float* sums, void* stream);
+
+/* The reference picks random voxels of a mask as `torch.where(mask)` + `torch.randperm(count)[:k]`
+ * (simulate_reco.py:661-664, augmentation/artifacts.py:110-113, :199-202, :565-567), materialising three int64 index
+ * lists of the whole mask.  Here: per-bucket counts (buckets of FSG_NZ_BUCKET = 4096 voxels, raster order), a host
+ * prefix sum, then the flat index of the rank[q]-th voxel of bucket[q] satisfying the predicate for each request
+ * (-1 if the bucket holds fewer).  Predicate on (float)v: mode 0: v > value, 1: v == value, 2: v != value. */
+#define FSG_NZ_BUCKET 4096
+int fsg_nonzero_count_f32(const float* v, size_t n, int mode, float value, int32_t* counts, void* stream);
+int fsg_nonzero_count_u8(const uint8_t* v, size_t n, int mode, float value, int32_t* counts, void* stream);
+int fsg_nonzero_select_f32(const float* v, size_t n, int mode, float value, const int32_t* bucket, const int32_t* rank,
+                           int nreq, long long* out, void* stream);
+int fsg_nonzero_select_u8(const uint8_t* v, size_t n, int mode, float value, const int32_t* bucket, const int32_t* rank,
+                          int nreq, long long* out, void* stream);
+
+/* out[offsets[b] + r] = values[e] for the r-th voxel e of bucket b with `pred[e]` satisfying the predicate: the
+ * boolean-mask gather `values[mask]` (augmentation/artifacts.py:78-80) in raster order; offsets = exclusive prefix sum
+ * of fsg_nonzero_count_f32's counts (DEVICE, int64). */
+int fsg_compact_f32(const float* values, const float* pred, size_t n, int mode, float value, const long long* offsets,
+                    float* out, void* stream);
+/* Element-wise glue of the artifact stages.  op 0: a + b; 1: (a > value) as 0/1; 2: (a == value) as 0/1; 3: a * b;
+ * 4: a * (b > value).  b may be NULL for ops 1 and 2. */
+int fsg_ewise_f32(const float* a, const float* b, size_t n, int op, float value, float* out, void* stream);
 
 /* ---- whole-sample launch sequence -------------------------------------------------------------------------- */
 /* One call = the fused kernel sequence of FetalSynthGen.sample (generator/model.py:231-276) for the

@@ -422,3 +422,86 @@ def slice_acq_adjoint_cuda(transforms, psf, slices, slices_mask, vol_mask, vol_s
         m = vw > 0
         vol[m] = vol[m] / vw[m]
     return vol.reshape(vol_shape), vw.reshape(vol_shape)
+
+
+# --------------------------------------------------------------------------------------
+# volumetric helpers of the artifact stages (generator/artifacts/utils.py) -- PINNED by tests/golden/sr_units.npz
+# --------------------------------------------------------------------------------------
+def mog3d(shape, centers, sigmas):
+    """clamp(sum_g exp(-d_g^2/2), 0, 1); a centre is unpacked (x0,y0,z0) with x the LAST axis (utils.py:125-160)."""
+    D, H, W = shape
+    z, y, x = torch.meshgrid(torch.arange(D).float(), torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    c = np.asarray(centers, dtype=np.float32).reshape(-1, 3)
+    s = np.broadcast_to(np.asarray(sigmas, dtype=np.float32).reshape(len(c), -1), (len(c), 3))
+    out = torch.zeros((D, H, W))
+    for (x0, y0, z0), (sx, sy, sz) in zip(c, s):
+        d = ((x - float(x0)) / float(sx)) ** 2 + ((y - float(y0)) / float(sy)) ** 2 + ((z - float(z0)) / float(sz)) ** 2
+        out += torch.exp(-d / 2)
+    return torch.clamp(out, 0, 1)
+
+
+def perlin_lattice(res):
+    """rand(theta), rand(phi) from the torch global generator -> unit gradients, tileable wrap (utils.py:266-283)."""
+    r0, r1, r2 = res
+    th = 2 * torch.pi * torch.rand(r0 + 1, r1 + 1, r2 + 1)
+    ph = 2 * torch.pi * torch.rand(r0 + 1, r1 + 1, r2 + 1)
+    g = torch.stack((torch.sin(ph) * torch.cos(th), torch.sin(ph) * torch.sin(th), torch.cos(ph)), -1)
+    g[-1] = g[0]
+    g[:, -1] = g[:, 0]
+    g[:, :, -1] = g[:, :, 0]
+    return g
+
+
+def perlin_octave(shape, res, g):
+    """One octave on `shape` with lattice `g` (utils.py:255-327)."""
+    lin = [torch.linspace(0, res[i], shape[i]) for i in range(3)]
+    grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
+    cell = grid.floor().long()
+    loc = grid - cell
+    rr = torch.tensor(res)
+
+    def corner(dx, dy, dz):
+        i0 = (cell[..., 0] + dx).clamp(max=res[0])
+        i1 = (cell[..., 1] + dy).clamp(max=res[1])
+        i2 = (cell[..., 2] + dz).clamp(max=res[2])
+        d = loc - torch.tensor([float(dx), float(dy), float(dz)])
+        return (g[i0, i1, i2] * d).sum(-1)
+
+    t = loc * loc * loc * (loc * (loc * 6 - 15) + 10)
+    n00 = corner(0, 0, 0) * (1 - t[..., 0]) + t[..., 0] * corner(1, 0, 0)
+    n10 = corner(0, 1, 0) * (1 - t[..., 0]) + t[..., 0] * corner(1, 1, 0)
+    n01 = corner(0, 0, 1) * (1 - t[..., 0]) + t[..., 0] * corner(1, 0, 1)
+    n11 = corner(0, 1, 1) * (1 - t[..., 0]) + t[..., 0] * corner(1, 1, 1)
+    n0 = n00 * (1 - t[..., 1]) + t[..., 1] * n10
+    n1 = n01 * (1 - t[..., 1]) + t[..., 1] * n11
+    return n0 * (1 - t[..., 2]) + t[..., 2] * n1
+
+
+def fractal_noise(shape, res, octaves, persistence, lacunarity, increase, lattices=None):
+    """generate_fractal_noise_3d (utils.py:330-388) minus its wall-clock re-seed of numpy; lattices drawn from the
+    torch global generator in octave order unless given.  Returns (normalised [0,1] field, raw field)."""
+    noise = torch.zeros(shape)
+    f, a = 1, 1.0
+    for q in range(octaves):
+        r = (f * res, f * res, f * res)
+        g = lattices[q] if lattices is not None else perlin_lattice(r)
+        noise += a * perlin_octave(shape, r, g)
+        f *= lacunarity
+        a *= persistence
+    out = (noise + increase - noise.min()) / (noise.max() - noise.min())
+    return torch.clamp(out, 0, 1), noise
+
+
+def rician(slices, thr, sigma, z1, z2):
+    """Scanner.add_noise (simulate_reco.py:247-255) with dense noise fields z1, z2 (used where slices > thr)."""
+    s = torch.as_tensor(slices).clone()
+    m = s > thr
+    s[m] = torch.sqrt((s[m] + torch.as_tensor(z1)[m] * sigma) ** 2 + (torch.as_tensor(z2)[m] * sigma) ** 2)
+    return s
+
+
+def box_mean3(v):
+    """PSFReconstructor.smooth_volume (simulate_reco.py:584-595)."""
+    import torch.nn.functional as TF
+
+    return TF.conv3d(torch.as_tensor(v)[None, None], torch.ones(1, 1, 3, 3, 3) / 27, padding=1)[0, 0]

@@ -86,7 +86,13 @@ def install_stubs():
     mod("nibabel")
     hu = mod("hydra.utils", instantiate=None)
     mod("hydra", utils=hu)
-    sm = mod("skimage.morphology", ball=None)
+    def ball(radius, dtype=np.uint8):
+        """skimage.morphology.ball: voxels within `radius` of the centre of a (2r+1)^3 cube."""
+        n = 2 * radius + 1
+        Z, Y, X = np.mgrid[-radius : radius : n * 1j, -radius : radius : n * 1j, -radius : radius : n * 1j]
+        return np.array(X**2 + Y**2 + Z**2 <= radius * radius, dtype=dtype)
+
+    sm = mod("skimage.morphology", ball=ball)
     mod("skimage", morphology=sm)
 
 
@@ -571,7 +577,189 @@ def g_slice_acq(R):
     save("slice_acq", **out)
 
 
+# --------------------------------------------------------------------------------------
+# SR-artifact stages (SURVEY.md 8(f)): reference run on CPU (torch fallbacks of the CUDA extension)
+# --------------------------------------------------------------------------------------
+FIXED_CLOCK = 1700000000  # generate_fractal_noise_3d re-seeds numpy from int(time.time()) (artifacts/utils.py:365-367)
+
+
+def _ref_sr():
+    import importlib
+
+    M = types.SimpleNamespace()
+    M.AU = importlib.import_module("fetalsyngen.generator.artifacts.utils")
+    M.SR = importlib.import_module("fetalsyngen.generator.artifacts.simulate_reco")
+    M.FM = importlib.import_module("fetalsyngen.generator.artifacts.svort.data.fetal_motion")
+    M.TR = importlib.import_module("fetalsyngen.generator.artifacts.svort.transform.transform")
+    M.ART = importlib.import_module("fetalsyngen.generator.augmentation.artifacts")
+    # the shipped trajectories (svort/data/traj.npy) are a pickle and are not loaded; the reference's sample_motion
+    # code runs on the synthetic bank this repo uses in their place
+    from fetalsyngen_amd.generator.artifacts.svort.scan import synthetic_trajectory_bank
+
+    bank = synthetic_trajectory_bank()
+    M.FM.get_trajectory = lambda: bank
+    M.AU.time = types.SimpleNamespace(time=lambda: FIXED_CLOCK)
+    return M
+
+
+def _phantom(n, rng):
+    """[0,1] image + label map 0..7 (nested shells; 2 = 'cortex', 3 = 'white matter') on an n^3 grid."""
+    g = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float32) - (n - 1) / 2] * 3, indexing="ij"))
+    r = np.sqrt((g[0] / 1.0) ** 2 + (g[1] / 0.9) ** 2 + (g[2] / 0.8) ** 2) / (n / 2)
+    seg = np.zeros((n, n, n), np.float32)
+    for lab, rad in ((1, 0.85), (2, 0.75), (3, 0.62), (4, 0.40), (5, 0.30), (6, 0.2), (7, 0.1)):
+        seg[r < rad] = lab
+    img = (0.15 + 0.1 * seg) * (seg > 0) + 0.03 * rng.standard_normal((n, n, n)).astype(np.float32) * (seg > 0)
+    img = np.clip(img, 0, None)
+    return (img / img.max()).astype(np.float32), seg
+
+
+def _next_draws():
+    return np.array([np.random.rand(), float(torch.rand(1))])
+
+
+def g_sr_units(R):
+    """mog_3d_tensor, Perlin noise, axis-angle algebra, random stacks, scanner corruptions."""
+    M = _ref_sr()
+    out = {}
+    rng = np.random.default_rng(3)
+    # -- MoG (artifacts/utils.py:125-160)
+    centers = [(3, 10, 20), (15.5, 2, 7), (22, 17, 1)]
+    out["mog_centers"] = np.array(centers, np.float32)
+    out["mog_a"] = M.AU.mog_3d_tensor((24, 20, 28), centers, 4.0, "cpu").numpy()
+    sig = np.array([[2.0, 3.0, 4.0], [5.0, 1.5, 2.5], [3.0, 3.0, 9.0]])
+    out["mog_sig"] = sig
+    out["mog_b"] = M.AU.mog_3d_tensor((24, 20, 28), centers, sig, "cpu").numpy()
+    out["mog_c"] = M.AU.mog_3d_tensor((24, 20, 28), centers, [torch.tensor([6.0]), torch.tensor([2.0]), torch.tensor([11.0])], "cpu").numpy()
+    # -- Perlin (artifacts/utils.py:224-388)
+    for tag, (shape, res, octv, inc) in {"p1": ((32, 32, 32), 2, 2, 0.1), "p2": ((48, 32, 16), 1, 4, 0.25),
+                                         "p3": ((24, 24, 24), 2, 1, 0.0)}.items():
+        torch.manual_seed(17)
+        np.random.seed(5)
+        n = M.AU.generate_fractal_noise_3d(shape, (res, res, res), octaves=octv, persistence=0.5, lacunarity=2,
+                                           increase=inc, device="cpu")
+        out[f"perlin_{tag}"] = n.numpy()
+        out[f"perlin_{tag}_cfg"] = np.array([*shape, res, octv, inc], np.float64)
+        out[f"perlin_{tag}_next"] = _next_draws()
+    # -- rigid algebra (transform/transform_convert.py, transform/transform.py)
+    ax = np.concatenate([rng.uniform(-3, 3, (40, 3)), rng.uniform(-30, 30, (40, 3))], 1).astype(np.float32)
+    ax[0, :3] = 0
+    ax[1, :3] = 2e-4
+    ax[2, :3] = [np.pi * 0.999, 0, 0]
+    ax[3, :3] = [0, 3.1, 0.01]
+    TC = sys.modules["fetalsyngen.generator.artifacts.svort.transform.transform_convert"]
+    m = TC.axisangle2mat_cpu(torch.from_numpy(ax))
+    out["ax"], out["ax_mat"], out["ax_back"] = ax, m.numpy(), TC.mat2axisangle_cpu(m).numpy()
+    a, b = M.TR.RigidTransform(torch.from_numpy(ax[:20])), M.TR.RigidTransform(m[20:], trans_first=False)
+    out["compose"] = a.compose(b).matrix().numpy()
+    out["inv"] = a.inv().matrix().numpy()
+    out["b_ax_first"] = b.axisangle(trans_first=True).numpy()
+    np.random.seed(11)
+    st = M.TR.random_init_stack_transforms(9, 2.5, False, 3.0, "cpu")
+    out["stack_ax"] = st.axisangle().numpy()
+    out["stack_reset"] = M.TR.reset_transform(st[torch.tensor([False, True, True, True, True, False, False, False, False])]).axisangle().numpy()
+    out["stack_upd"] = M.TR.mat_update_resolution(st.matrix(), 0.8, 0.5).numpy()
+    mo = M.FM.sample_motion(np.arange(9) * 1.3, "cpu", True)
+    out["motion"] = mo.matrix().numpy()
+    out["units_next"] = _next_draws()
+    # -- scanner corruptions (simulate_reco.py:210-298)
+    sc = M.SR.Scanner(0.5, 2, 1.5, 1.5, 3.5, 1.5, 5.5, 2, 6, 250, 0.0, 0.1, 1, 2, prob_gamma=1.0, gamma_std=0.05,
+                      prob_void=0.5, slice_size=None, restrict_transform=False, txy=3.0)
+    s0 = (rng.random((7, 1, 20, 24), dtype=np.float32) * (rng.random((7, 1, 20, 24)) > 0.3)).astype(np.float32)
+    out["slices_in"] = s0
+    np.random.seed(21)
+    torch.manual_seed(22)
+    s1 = sc.random_gamma(torch.from_numpy(s0.copy()))
+    out["slices_gamma"] = s1.numpy()
+    s2 = sc.add_noise(s1.clone())
+    out["slices_noise"] = s2.numpy()
+    s3 = sc.signal_void(s2.clone())
+    out["slices_void"] = s3.numpy()
+    out["corrupt_next"] = _next_draws()
+    save("sr_units", **out)
+
+
+SCANNER_KW = dict(resolution_slice_fac_min=0.5, resolution_slice_fac_max=2, resolution_slice_max=1.5, slice_thickness_min=1.5,
+                  slice_thickness_max=3.5, gap_min=1.5, gap_max=5.5, min_num_stack=2, max_num_stack=6, max_num_slices=250,
+                  noise_sigma_min=0, noise_sigma_max=0.1, TR_min=1, TR_max=2, prob_void=0.2, prob_gamma=0.1, gamma_std=0.05,
+                  slice_size=None, restrict_transform=False, txy=3.0)
+MERGE_KW = dict(perlin_res_list=[1, 2], perlin_octaves_list=[1, 2, 4], perlin_persistence=0.5, perlin_lacunarity=2,
+                gauss_ngaussians_min=2, gauss_ngaussians_max=4, perlin_increase_size=0.25)
+RECON_KW = dict(prob_misreg_slice=0.1, slices_misreg_ratio=0.1, prob_misreg_stack=0.1, txy=3.0, prob_merge=1.0, prob_smooth=0.2,
+                prob_rm_slices=0.3, rm_slices_min=0.1, rm_slices_max=0.4)
+
+
+def g_sr_motion(R):
+    """Scanner.scan + PSFReconstructor.recon_psf and SimulateMotion.__call__ on a 32^3 phantom, CPU."""
+    M = _ref_sr()
+    rng = np.random.default_rng(8)
+    img, seg = _phantom(32, rng)
+    out = {"img": img, "seg": seg}
+    for case, (seed, merge_type, over) in {"a": (1, "perlin", {}), "b": (4, "gaussian", dict(prob_smooth=1.0, prob_rm_slices=1.0,
+                                                                                           prob_misreg_stack=1.0, prob_misreg_slice=1.0)),
+                                           "c": (6, "perlin", dict(prob_merge=0.0))}.items():
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        sp = M.AU.ScannerParams(**{**SCANNER_KW, "prob_gamma": 0.5, "prob_void": 0.5})
+        rp = M.AU.ReconParams(**{**RECON_KW, **over}, merge_params=M.AU.ReconMergeParams(merge_type=merge_type, **MERGE_KW))
+        sm = M.ART.SimulateMotion(prob=1.0, scanner_params=sp, recon_params=rp)
+        y, meta = sm(torch.from_numpy(img.copy()), torch.from_numpy(seg.copy()), "cpu", {}, resolution=[0.5, 0.5, 0.5])
+        out[f"{case}_out"] = y.numpy()
+        out[f"{case}_next"] = _next_draws()
+        for k, v in meta.items():
+            if k == "misreg_stack_on":
+                v = np.array(v, dtype=np.int64)
+            elif isinstance(v, str):
+                v = np.array(v)
+            elif v is None:
+                v = np.array(np.nan)
+            out[f"{case}_meta_{k}"] = np.asarray(v)
+    # one explicit scan, to pin the intermediate slice stacks and transforms
+    np.random.seed(13)
+    torch.manual_seed(13)
+    d = {"resolution": np.float64(0.5), "volume": torch.from_numpy(img.copy())[None, None],
+         "mask": torch.from_numpy((seg > 0).astype(np.float32))[None, None], "seg": torch.from_numpy(seg.copy())[None, None],
+         "threshold": 0.1}
+    sc = M.SR.Scanner(**{**SCANNER_KW, "prob_gamma": 0.5, "prob_void": 0.5, "resolution_recon": np.float64(0.5)})
+    ds = sc.scan(d)
+    out["scan_stacks"] = ds["stacks"].numpy()[:, 0]
+    out["scan_stacks_no_psf"] = ds["stacks_no_psf"].numpy()[:, 0]
+    out["scan_positions"] = ds["positions"].numpy()
+    out["scan_transforms"] = ds["transforms"].numpy()
+    out["scan_transforms_gt"] = ds["transforms_gt"].numpy()
+    out["scan_psf_rec"] = ds["psf_rec"].numpy()
+    out["scan_meta"] = np.array([ds["resolution_slice"], ds["slice_thickness"], ds["gap"]])
+    out["scan_next"] = _next_draws()
+    save("sr_motion", **out)
+
+
+def g_sr_volumetric(R):
+    """BlurCortex and StructNoise (augmentation/artifacts.py:24-342) on a 48^3 phantom, CPU."""
+    M = _ref_sr()
+    rng = np.random.default_rng(9)
+    img, seg = _phantom(48, rng)
+    out = {"img": img, "seg": seg}
+    for case, seed in {"a": 2, "b": 5}.items():
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        bc = M.ART.BlurCortex(prob=1.0, cortex_label=2, nblur_min=4, nblur_max=12)
+        y, meta = bc(torch.from_numpy(img.copy()), torch.from_numpy(seg.copy()), "cpu", {})
+        out[f"blur_{case}"], out[f"blur_{case}_nblur"], out[f"blur_{case}_next"] = y.numpy(), np.int64(meta["nblur"]), _next_draws()
+    for case, (seed, mt) in {"a": (3, "perlin"), "b": (7, "gaussian"), "c": (12, "perlin")}.items():
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        mp = M.AU.StructNoiseMergeParams(merge_type=mt, gauss_nloc_min=5, gauss_nloc_max=15, gauss_sigma_mu=25, gauss_sigma_std=5,
+                                         perlin_res_list=[1, 2], perlin_octaves_list=[1, 2, 4], perlin_persistence=0.5,
+                                         perlin_lacunarity=2, perlin_increase_size=0.1)
+        sn = M.ART.StructNoise(prob=1.0, wm_label=3, std_min=0.2, std_max=0.4, merge_params=mp, nstages_min=1, nstages_max=5)
+        y, meta = sn(torch.from_numpy(img.copy()), torch.from_numpy(seg.copy()), "cpu", {})
+        out[f"sn_{case}"], out[f"sn_{case}_next"] = y.numpy(), _next_draws()
+        out[f"sn_{case}_meta"] = np.array([meta["nstages"], meta["noise_std"]])
+    save("sr_volumetric", **out)
+
+
 ALL = {
+    "sr_units": g_sr_units, "sr_motion": g_sr_motion, "sr_volumetric": g_sr_volumetric,
     "slice_acq": g_slice_acq,
     "affine": g_affine, "gauss": g_gauss, "blur": g_blur, "zoom": g_zoom, "interp": g_interp,
     "deform_image": g_deform_image, "gmm": g_gmm, "stages": g_stages, "e2e": g_e2e,

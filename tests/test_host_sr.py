@@ -1,0 +1,94 @@
+"""CPU: host-side logic of the SR-artifact stages (rigid-transform algebra, stack geometry, motion sampling,
+interpolation tables) against the golden vectors captured from the reference (tests/golden/sr_units.npz)."""
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from fetalsyngen_amd.generator.artifacts import svort as SV
+from fetalsyngen_amd.generator.artifacts.svort import rigid
+
+
+def test_axisangle_conversions_bit_exact(golden):
+    g = golden("sr_units")
+    ax = torch.from_numpy(g["ax"])
+    m = rigid.axisangle2mat(ax)
+    assert np.array_equal(m.numpy(), g["ax_mat"])
+    assert np.array_equal(rigid.mat2axisangle(m).numpy(), g["ax_back"])
+
+
+def test_rigid_transform_class(golden):
+    g = golden("sr_units")
+    ax = torch.from_numpy(g["ax"])
+    m = rigid.axisangle2mat(ax)
+    a, b = SV.RigidTransform(ax[:20]), SV.RigidTransform(m[20:], trans_first=False)
+    assert np.array_equal(a.compose(b).matrix().numpy(), g["compose"])
+    assert np.array_equal(a.inv().matrix().numpy(), g["inv"])
+    assert np.array_equal(b.axisangle(trans_first=True).numpy(), g["b_ax_first"])
+    assert len(a) == 20 and len(a[3]) == 1 and len(a[2:5]) == 3
+    assert np.array_equal(SV.RigidTransform.cat([a, a.inv()]).matrix()[:20].numpy(), a.matrix().numpy())
+
+
+def test_stack_geometry_and_motion_replay_reference_draws(golden):
+    """Same numpy draw order as the reference: random_init_stack_transforms -> sample_motion -> next draw."""
+    g = golden("sr_units")
+    np.random.seed(11)
+    st = SV.random_init_stack_transforms(9, 2.5, False, 3.0, "cpu")
+    assert np.array_equal(st.axisangle().numpy(), g["stack_ax"])
+    keep = torch.tensor([False, True, True, True, True, False, False, False, False])
+    assert np.array_equal(SV.reset_transform(st[keep]).axisangle().numpy(), g["stack_reset"])
+    assert np.array_equal(SV.mat_update_resolution(st.matrix(), 0.8, 0.5).numpy(), g["stack_upd"])
+    mo = SV.sample_motion(np.arange(9) * 1.3, "cpu", True)
+    assert np.array_equal(mo.matrix().numpy(), g["motion"])
+    assert np.random.rand() == g["units_next"][0]
+
+
+def test_psf_and_interleave(golden):
+    g = golden("slice_acq")
+    assert np.array_equal(SV.get_PSF(res_ratio=(1, 1, 3)).numpy(), g["psf_aniso"])
+    assert np.array_equal(SV.get_PSF(res_ratio=(1.2, 1.2, 1.2)).numpy(), g["psf_iso"])
+    assert tuple(SV.get_PSF(0).shape) == (1, 1, 1)
+    assert SV.interleave_index(7, 3) == [0, 3, 5, 1, 4, 6, 2]
+
+
+def _apply_tables(x, tabs):
+    for axis, t in enumerate(tabs):
+        lo = np.take(x, t["lo"], axis=axis)
+        hi = np.take(x, t["hi"], axis=axis)
+        shp = [1, 1, 1]
+        shp[axis] = -1
+        x = lo * t["w_lo"].reshape(shp) + hi * t["w_hi"].reshape(shp)
+    return x
+
+
+def test_trilinear_interpolate_tables_match_torch():
+    """StructNoise doubles its noise grid with F.interpolate(trilinear, align_corners=False)
+    (augmentation/artifacts.py:315-320); the zoom kernel is driven by these per-axis tables."""
+    from fetalsyngen_amd.generator.augmentation.artifacts import _interp_tables
+
+    rng = np.random.default_rng(0)
+    for s_in, s_out in (((3, 3, 3), (6, 6, 6)), ((6, 5, 4), (12, 10, 8)), ((24, 24, 24), (48, 48, 48)), ((5, 7, 3), (11, 15, 7))):
+        x = rng.standard_normal(s_in).astype(np.float32)
+        ref = TF.interpolate(torch.from_numpy(x)[None, None], size=s_out, mode="trilinear", align_corners=False)[0, 0].numpy()
+        got = _apply_tables(x, [_interp_tables(a, b) for a, b in zip(s_in, s_out)])
+        np.testing.assert_allclose(got, ref, atol=1e-6)
+
+
+def test_grid_resample_tables_match_grid_sample():
+    """Scanner.scan resamples the ground truth with F.grid_sample when the reconstruction grid is coarser
+    (simulate_reco.py:319-328)."""
+    from fetalsyngen_amd.generator.artifacts.simulate_reco import _axis_resample_tables
+
+    rng = np.random.default_rng(1)
+    vs, res, res_r = (12, 10, 14), 0.5, 0.8
+    x = rng.random(vs, dtype=np.float32)
+    grids = []
+    for i in range(3):
+        size_new = int(vs[i] * res / res_r)
+        gmax = (size_new - 1) * res_r / (vs[i] - 1) / res
+        grids.append(torch.linspace(-gmax, gmax, size_new))
+    grid = torch.stack(torch.meshgrid(*grids, indexing="ij")[::-1], -1).unsqueeze(0)
+    for nearest in (False, True):
+        ref = TF.grid_sample(torch.from_numpy(x)[None, None], grid, mode="nearest" if nearest else "bilinear",
+                             align_corners=True)[0, 0].numpy()
+        got = _apply_tables(x, [_axis_resample_tables(vs[i], res, res_r, nearest) for i in range(3)])
+        np.testing.assert_allclose(got, ref, atol=1e-6)

@@ -79,3 +79,33 @@ def test_rigid_algebra_roundtrip():
 def test_interleave_index():
     assert S.interleave_index(7, 3) == [0, 3, 5, 1, 4, 6, 2]
     assert sorted(S.interleave_index(11, 2)) == list(range(11))
+
+
+# ---- volumetric helpers of the artifact stages, pinned by tests/golden/sr_units.npz ---------------------------
+def test_mog_pinned(golden):
+    g = golden("sr_units")
+    c = g["mog_centers"]
+    np.testing.assert_allclose(S.mog3d((24, 20, 28), c, np.full((3, 1), 4.0)).numpy(), g["mog_a"], atol=1e-6)
+    np.testing.assert_allclose(S.mog3d((24, 20, 28), c, g["mog_sig"]).numpy(), g["mog_b"], atol=1e-6)
+    np.testing.assert_allclose(S.mog3d((24, 20, 28), c, np.array([[6.0], [2.0], [11.0]])).numpy(), g["mog_c"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["p1", "p2", "p3"])
+def test_perlin_pinned(golden, tag):
+    g = golden("sr_units")
+    cfg = g[f"perlin_{tag}_cfg"]
+    shape, res, octv, inc = tuple(int(v) for v in cfg[:3]), int(cfg[3]), int(cfg[4]), float(cfg[5])
+    torch.manual_seed(17)
+    n, _ = S.fractal_noise(shape, res, octv, 0.5, 2, inc)
+    np.testing.assert_allclose(n.numpy(), g[f"perlin_{tag}"], atol=2e-6)
+    assert float(torch.rand(1)) == g[f"perlin_{tag}_next"][1]  # same number of torch draws consumed
+
+
+def test_rigid_algebra_pinned(golden):
+    g = golden("sr_units")
+    ax = torch.from_numpy(g["ax"])
+    m = S.axisangle2mat(ax)
+    assert np.array_equal(m.numpy(), g["ax_mat"])
+    assert np.array_equal(S.mat2axisangle(m).numpy(), g["ax_back"])
+    a, b = S.axisangle2mat(ax[:20]), S.mat_last2first(m[20:])
+    assert np.array_equal(S.compose(a, b).numpy(), g["compose"])

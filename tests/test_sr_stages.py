@@ -1,0 +1,192 @@
+"""GPU parity of the SR-artifact stages against golden vectors captured from a CPU run of the
+reference (tests/golden/sr_units.npz, sr_motion.npz, sr_volumetric.npz; generator: tests/golden/make_golden.py).
+
+The CPU run of the reference goes through its torch fallbacks, so these tests select `semantics="torch"` for the
+slice acquisition and `rng="reference"` (host-tape noise).  Tolerances, on [0,1] images:
+  * MoG / Perlin weight fields: atol 2e-6 / 1e-5;
+  * slice corruptions: atol 2e-6 (gamma through v_log/v_exp: 2e-5);
+  * end-to-end SimulateMotion: atol 2e-4 (nearest-voxel scatter + equalisation amplify fp32 summation-order noise where
+    the accumulated weight is close to the 1e-2 equalisation threshold);
+  * BlurCortex / StructNoise: atol 2e-5.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FIXED_CLOCK = 1700000000
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device (and libfsg_hip.so); there is no fallback to skip to")
+    from fetalsyngen_amd import kernels, rng
+    from fetalsyngen_amd.generator.artifacts import simulate_reco, utils
+    from fetalsyngen_amd.generator.artifacts.svort import slice_acq as sa
+    from fetalsyngen_amd.generator.augmentation import artifacts
+
+    utils.time = types.SimpleNamespace(time=lambda: FIXED_CLOCK)  # the reference re-seeds numpy from the clock
+    prev_sem, prev_rng = sa.set_semantics("torch"), rng.get_mode()
+    rng.set_mode("reference")
+    yield types.SimpleNamespace(K=kernels, U=utils, SR=simulate_reco, ART=artifacts)
+    sa.set_semantics(prev_sem)
+    rng.set_mode(prev_rng)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(x):
+    return x.detach().cpu().numpy()
+
+
+def next_draws():
+    return np.array([np.random.rand(), float(torch.rand(1))])
+
+
+# ---- weight fields ------------------------------------------------------------------------------------------
+def test_mog_vs_reference(env, golden):
+    g = golden("sr_units")
+    c = [tuple(v) for v in g["mog_centers"].tolist()]
+    np.testing.assert_allclose(host(env.U.mog_3d_tensor((24, 20, 28), c, 4.0, DEV)), g["mog_a"], atol=2e-6)
+    np.testing.assert_allclose(host(env.U.mog_3d_tensor((24, 20, 28), c, g["mog_sig"], DEV)), g["mog_b"], atol=2e-6)
+    sig = [torch.tensor([6.0]), torch.tensor([2.0]), torch.tensor([11.0])]
+    np.testing.assert_allclose(host(env.U.mog_3d_tensor((24, 20, 28), c, sig, DEV)), g["mog_c"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["p1", "p2", "p3"])
+def test_fractal_noise_vs_reference(env, golden, tag):
+    g = golden("sr_units")
+    cfg = g[f"perlin_{tag}_cfg"]
+    shape, res, octv, inc = tuple(int(v) for v in cfg[:3]), int(cfg[3]), int(cfg[4]), float(cfg[5])
+    torch.manual_seed(17)
+    np.random.seed(5)
+    n = env.U.generate_fractal_noise_3d(shape, (res, res, res), octaves=octv, persistence=0.5, lacunarity=2, increase=inc,
+                                        device=DEV)
+    np.testing.assert_allclose(host(n), g[f"perlin_{tag}"], atol=1e-5)
+    assert np.array_equal(next_draws(), g[f"perlin_{tag}_next"])  # same clock re-seed, same torch draws
+
+
+def test_fullsize_fields_properties(env):
+    """256^3: Perlin field spans exactly [0,1] after normalisation (increase=0) and is tileable; MoG peaks at its centres."""
+    torch.manual_seed(3)
+    n = env.U.generate_fractal_noise_3d((256, 256, 256), (2, 2, 2), octaves=4, persistence=0.5, lacunarity=2, increase=0.0,
+                                        device=DEV)
+    assert n.min().item() == 0.0 and n.max().item() == 1.0
+    assert torch.allclose(n[0], n[-1], atol=1e-5) and torch.allclose(n[:, :, 0], n[:, :, -1], atol=1e-5)
+    c = [(200, 30, 77), (10, 250, 128)]
+    m = env.U.mog_3d_tensor((256, 256, 256), c, [9.0, 3.0], DEV)
+    for (x0, y0, z0) in c:
+        assert abs(m[z0, y0, x0].item() - 1.0) < 1e-6  # (x0,y0,z0) pairs x with the LAST axis (reference convention)
+    assert m.max().item() <= 1.0 and m[128, 128, 128].item() < 1e-6
+
+
+# ---- scanner corruptions --------------------------------------------------------------------------------------
+def test_scanner_corruptions_vs_reference(env, golden):
+    g = golden("sr_units")
+    sc = env.SR.Scanner(0.5, 2, 1.5, 1.5, 3.5, 1.5, 5.5, 2, 6, 250, 0.0, 0.1, 1, 2, prob_gamma=1.0, gamma_std=0.05,
+                        prob_void=0.5, slice_size=None, restrict_transform=False, txy=3.0)
+    np.random.seed(21)
+    torch.manual_seed(22)
+    s1 = sc.random_gamma(dev(g["slices_in"]))
+    np.testing.assert_allclose(host(s1), g["slices_gamma"], atol=2e-5)
+    s2 = sc.add_noise(dev(g["slices_gamma"]))
+    np.testing.assert_allclose(host(s2), g["slices_noise"], atol=2e-6)
+    s3 = sc.signal_void(dev(g["slices_noise"]))
+    np.testing.assert_allclose(host(s3), g["slices_void"], atol=2e-6)
+    assert np.array_equal(next_draws(), g["corrupt_next"])
+
+
+# ---- SimulateMotion end to end --------------------------------------------------------------------------------
+SCANNER_KW = dict(resolution_slice_fac_min=0.5, resolution_slice_fac_max=2, resolution_slice_max=1.5, slice_thickness_min=1.5,
+                  slice_thickness_max=3.5, gap_min=1.5, gap_max=5.5, min_num_stack=2, max_num_stack=6, max_num_slices=250,
+                  noise_sigma_min=0, noise_sigma_max=0.1, TR_min=1, TR_max=2, prob_void=0.2, prob_gamma=0.1, gamma_std=0.05,
+                  slice_size=None, restrict_transform=False, txy=3.0)
+MERGE_KW = dict(perlin_res_list=[1, 2], perlin_octaves_list=[1, 2, 4], perlin_persistence=0.5, perlin_lacunarity=2,
+                gauss_ngaussians_min=2, gauss_ngaussians_max=4, perlin_increase_size=0.25)
+RECON_KW = dict(prob_misreg_slice=0.1, slices_misreg_ratio=0.1, prob_misreg_stack=0.1, txy=3.0, prob_merge=1.0, prob_smooth=0.2,
+                prob_rm_slices=0.3, rm_slices_min=0.1, rm_slices_max=0.4)
+CASES = {"a": (1, "perlin", {}),
+         "b": (4, "gaussian", dict(prob_smooth=1.0, prob_rm_slices=1.0, prob_misreg_stack=1.0, prob_misreg_slice=1.0)),
+         "c": (6, "perlin", dict(prob_merge=0.0))}
+
+
+def test_scan_intermediates_vs_reference(env, golden):
+    g = golden("sr_motion")
+    np.random.seed(13)
+    torch.manual_seed(13)
+    img, seg = dev(g["img"]), dev(g["seg"])
+    d = {"resolution": np.float64(0.5), "volume": img[None, None], "mask": (seg > 0).float()[None, None],
+         "seg": seg[None, None], "threshold": 0.1}
+    sc = env.SR.Scanner(**{**SCANNER_KW, "prob_gamma": 0.5, "prob_void": 0.5, "resolution_recon": np.float64(0.5)})
+    ds = sc.scan(d)
+    assert np.array_equal(np.array([ds["resolution_slice"], ds["slice_thickness"], ds["gap"]]), g["scan_meta"])
+    assert np.array_equal(host(ds["positions"]), g["scan_positions"])
+    # host algebra: bit-exact on the CPU the golden was made on (tests/test_host_sr.py); torch's vectorised sin/cos
+    # differ by an ulp between CPU generations, so the GPU box gets a tolerance
+    np.testing.assert_allclose(host(ds["transforms"]), g["scan_transforms"], atol=1e-5)
+    np.testing.assert_allclose(host(ds["transforms_gt"]), g["scan_transforms_gt"], atol=1e-5)
+    np.testing.assert_allclose(host(ds["psf_rec"]), g["scan_psf_rec"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(host(ds["stacks_no_psf"])[:, 0], g["scan_stacks_no_psf"], atol=2e-6)
+    d = np.abs(host(ds["stacks"])[:, 0] - g["scan_stacks"])
+    assert (d > 2e-5).mean() < 1e-3 and d.max() < 1e-2, (float((d > 2e-5).mean()), float(d.max()))
+    assert np.array_equal(next_draws(), g["scan_next"])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_simulate_motion_vs_reference(env, golden, case):
+    g = golden("sr_motion")
+    seed, merge_type, over = CASES[case]
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    sp = env.U.ScannerParams(**{**SCANNER_KW, "prob_gamma": 0.5, "prob_void": 0.5})
+    rp = env.U.ReconParams(**{**RECON_KW, **over}, merge_params=env.U.ReconMergeParams(merge_type=merge_type, **MERGE_KW))
+    sm = env.ART.SimulateMotion(prob=1.0, scanner_params=sp, recon_params=rp)
+    y, meta = sm(dev(g["img"]), dev(g["seg"]), DEV, {}, resolution=[0.5, 0.5, 0.5])
+    for k, v in meta.items():
+        ref = g[f"{case}_meta_{k}"]
+        if v is None:
+            assert np.isnan(ref)
+        elif isinstance(v, str):
+            assert str(ref) == v
+        else:
+            assert np.array_equal(np.asarray(v, dtype=ref.dtype), ref), k
+    assert np.array_equal(next_draws(), g[f"{case}_next"])
+    assert tuple(y.shape) == (32, 32, 32)
+    # nearest-voxel scatter: an ulp in a transform (libm differences between hosts) moves a sample that sits on a
+    # voxel boundary to the neighbouring voxel -- a handful of voxels may differ by more than the tolerance
+    d = np.abs(host(y) - g[f"{case}_out"])
+    assert (d > 2e-4).mean() < 1e-3 and d.max() < 1e-2, (float((d > 2e-4).mean()), float(d.max()))
+
+
+# ---- BlurCortex / StructNoise -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,seed", [("a", 2), ("b", 5)])
+def test_blur_cortex_vs_reference(env, golden, case, seed):
+    g = golden("sr_volumetric")
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    bc = env.ART.BlurCortex(prob=1.0, cortex_label=2, nblur_min=4, nblur_max=12)
+    y, meta = bc(dev(g["img"]), dev(g["seg"]), DEV, {})
+    assert meta["nblur"] == int(g[f"blur_{case}_nblur"])
+    assert np.array_equal(next_draws(), g[f"blur_{case}_next"])
+    np.testing.assert_allclose(host(y), g[f"blur_{case}"], atol=2e-5)
+
+
+@pytest.mark.parametrize("case,seed,mt", [("a", 3, "perlin"), ("b", 7, "gaussian"), ("c", 12, "perlin")])
+def test_struct_noise_vs_reference(env, golden, case, seed, mt):
+    g = golden("sr_volumetric")
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    mp = env.U.StructNoiseMergeParams(merge_type=mt, gauss_nloc_min=5, gauss_nloc_max=15, gauss_sigma_mu=25, gauss_sigma_std=5,
+                                      perlin_res_list=[1, 2], perlin_octaves_list=[1, 2, 4], perlin_persistence=0.5,
+                                      perlin_lacunarity=2, perlin_increase_size=0.1)
+    sn = env.ART.StructNoise(prob=1.0, wm_label=3, std_min=0.2, std_max=0.4, merge_params=mp, nstages_min=1, nstages_max=5)
+    y, meta = sn(dev(g["img"]), dev(g["seg"]), DEV, {})
+    assert np.array_equal(np.array([meta["nstages"], meta["noise_std"]]), g[f"sn_{case}_meta"])
+    assert np.array_equal(next_draws(), g[f"sn_{case}_next"])
+    np.testing.assert_allclose(host(y), g[f"sn_{case}"], atol=2e-5)
