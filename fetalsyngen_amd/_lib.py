@@ -140,6 +140,10 @@ SIGNATURES = {
     "fsg_nonzero_select_u8": [P, SZ, I, F, P, P, I, P, P],
     "fsg_compact_f32": [P, P, SZ, I, F, P, P, P],
     "fsg_ewise_f32": [P, P, SZ, I, F, P, P],
+    "fsg_dist_pass_f32": [P, P, I, I, I, I, I, I, I, P],
+    "fsg_boundary_mask_f32": [P, P, P, P, P, I, SZ, P, P, P],
+    "fsg_bernoulli_keep_f32": [P, SZ, F, U64, U64, P, P],
+    "fsg_scatter_const_f32": [P, P, I, F, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],

@@ -280,7 +280,8 @@ __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ v
   }
 }
 
-// small element-wise helpers: 0: a + b, 1: a > value, 2: a == value, 3: a * b, 4: a * (b > value)
+// small element-wise helpers: 0: a + b, 1: a > value, 2: a == value, 3: a * b, 4: a * (b > value), 5: max(a, b),
+// 6: (a - b) > value, 7: a <= value
 __global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int op,
                                                     float value, float* __restrict__ out) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -291,10 +292,86 @@ __global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ a,
       case 1: r = x > value ? 1.f : 0.f; break;
       case 2: r = x == value ? 1.f : 0.f; break;
       case 3: r = x * b[e]; break;
-      default: r = x * (b[e] > value ? 1.f : 0.f); break;
+      case 4: r = x * (b[e] > value ? 1.f : 0.f); break;
+      case 5: r = fmaxf(x, b[e]); break;
+      case 6: r = (x - b[e]) > value ? 1.f : 0.f; break;
+      default: r = x <= value ? 1.f : 0.f; break;
     }
     out[e] = r;
   }
+}
+
+
+// ---- distance passes: ball / octahedron dilation without the (2r+1)^3 convolution ---------------------------------
+// dst[v] = min over |t| <= r (inside the volume) of src'[v + t e_axis] + cost(t); cost = t^2 (squared Euclidean) or |t|
+// (city block).  first: src is a mask (set -> 0, unset -> BIG).  Three passes (one per axis) give the exact squared
+// Euclidean / city-block distance to the mask wherever it is <= r^2 / r: thresholding it is the zero-padded conv3d with
+// skimage's ball(r) > 0 (artifacts.py:484-499), respectively r repeated ball(1) dilations (artifacts.py:587-589).
+constexpr float DIST_BIG = 1e9f;
+
+__global__ __launch_bounds__(256) void dist_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1,
+                                                        int n2, int axis, int r, int metric, int first) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y, i = blockIdx.z;
+  if (k >= n2) return;
+  const size_t v = ((size_t)i * n1 + j) * n2 + k;
+  const int pos = axis == 0 ? i : (axis == 1 ? j : k);
+  const int len = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+  const long long stride = axis == 0 ? (long long)n1 * n2 : (axis == 1 ? n2 : 1);
+  const int lo = max(-r, -pos), hi = min(r, len - 1 - pos);
+  float best = DIST_BIG;
+  for (int t = lo; t <= hi; ++t) {
+    float s = src[(long long)v + t * stride];
+    if (first) s = s > 0.f ? 0.f : DIST_BIG;
+    const float c = metric == 0 ? (float)(t * t) : (float)abs(t);
+    best = fminf(best, s + c);
+  }
+  dst[v] = best;
+}
+
+// SimulatedBoundaries, fuzzy branch (artifacts.py:565-602) fused: the reference stacks n_dilate successive dilations of
+// `mask`, picks one per voxel through a one-hot of the rounded probability map and multiplies by mask_modif.
+// stack[k] = {city-block distance to mask <= max(k-1, 0)}, so with k = clamp(rint(p * n_dilate - 1), 0):
+//   out = image * mask_modif * (dist <= max(k - 1, 0)),  p = mog on the voxels mask_modif added to mask, 0 elsewhere.
+__global__ __launch_bounds__(256) void boundary_mask_kernel(const float* __restrict__ image, const float* __restrict__ mask,
+                                                            const float* __restrict__ mask_modif, const float* __restrict__ mog,
+                                                            const float* __restrict__ dist, int n_dilate, size_t n,
+                                                            float* __restrict__ out, float* __restrict__ mask_out) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float mm = mask_modif[e];
+    const bool surf = (mm - mask[e]) > 0.f;
+    const float p = surf ? mog[e] : 0.f;
+    int k = (int)rintf(p * (float)n_dilate - 1.f);
+    if (k < 0) k = 0;
+    const float thr = (float)(k > 1 ? k - 1 : 0);
+    const float m = mm * (dist[e] <= thr ? 1.f : 0.f);
+    if (out) out[e] = image[e] * m;
+    if (mask_out) mask_out[e] = m;
+  }
+}
+
+// out[e] = a[e] * (u_e < p), u from Philox(seed, stream_id): random thinning of a shell (device-RNG stand-in for
+// `diff[randperm(n)[: int(0.9 n)]] = 0`, artifacts.py:515-518)
+__global__ __launch_bounds__(256) void bernoulli_kernel(const float* __restrict__ a, size_t n, float p, uint64_t seed,
+                                                        uint64_t stream_id, float* __restrict__ out) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float x = a[e];
+    float r = 0.f;
+    if (x != 0.f) {
+      const uint64_t blk = e >> 2;
+      const uint4 q = fsg_philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                                        (uint32_t)seed, (uint32_t)(seed >> 32));
+      const uint32_t w = (e & 3) == 0 ? q.x : ((e & 3) == 1 ? q.y : ((e & 3) == 2 ? q.z : q.w));
+      r = ((float)(w >> 8) * 5.9604644775390625e-08f) < p ? x : 0.f;
+    }
+    out[e] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_const_kernel(float* __restrict__ out, const long long* __restrict__ idx, int k,
+                                                            float value) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < k && idx[q] >= 0) out[idx[q]] = value;
 }
 
 }  // namespace
@@ -411,11 +488,49 @@ int fsg_compact_f32(const float* values, const float* pred, size_t n, int mode, 
 }
 
 int fsg_ewise_f32(const float* a, const float* b, size_t n, int op, float value, float* out, void* stream) {
-  if (!a || !out || n == 0 || op < 0 || op > 4) return FSG_E_BADARG;
-  if ((op == 0 || op >= 3) && !b) return FSG_E_BADARG;
+  if (!a || !out || n == 0 || op < 0 || op > 7) return FSG_E_BADARG;
+  if ((op == 0 || (op >= 3 && op <= 6)) && !b) return FSG_E_BADARG;
   size_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), a, b, n, op, value, out);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_dist_pass_f32(const float* src, float* dst, int n0, int n1, int n2, int axis, int radius, int metric, int first,
+                      void* stream) {
+  if (!src || !dst || src == dst || n0 <= 0 || n1 <= 0 || n2 <= 0 || axis < 0 || axis > 2 || radius < 0 || radius > 1024 ||
+      metric < 0 || metric > 1)
+    return FSG_E_BADARG;
+  if ((size_t)n0 * n1 * n2 > (size_t)0x7FFFFFFF || n0 > 65535 || n1 > 65535) return FSG_E_TOOBIG;
+  const int tx = n2 > 128 ? 256 : (n2 > 64 ? 128 : 64);
+  hipLaunchKernelGGL(dist_pass_kernel, dim3((unsigned)((n2 + tx - 1) / tx), (unsigned)n1, (unsigned)n0), dim3(tx), 0,
+                     fsg_stream(stream), src, dst, n0, n1, n2, axis, radius, metric, first);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_boundary_mask_f32(const float* image, const float* mask, const float* mask_modif, const float* mog, const float* dist,
+                          int n_dilate, size_t n, float* out, float* mask_out, void* stream) {
+  if (!mask || !mask_modif || !mog || !dist || n == 0 || n_dilate <= 0 || (!out && !mask_out) || (out && !image))
+    return FSG_E_BADARG;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(boundary_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), image, mask, mask_modif,
+                     mog, dist, n_dilate, n, out, mask_out);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_bernoulli_keep_f32(const float* a, size_t n, float p, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+  if (!a || !out || n == 0) return FSG_E_BADARG;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(bernoulli_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), a, n, p, seed, stream_id, out);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_scatter_const_f32(float* out, const long long* idx, int k, float value, void* stream) {
+  if (!out || !idx || k <= 0) return FSG_E_BADARG;
+  hipLaunchKernelGGL(scatter_const_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, fsg_stream(stream), out, idx, k,
+                     value);
   FSG_RETURN_LAUNCH();
 }
 

@@ -224,3 +224,89 @@ class SimulateMotion(RandTransform):
             metadata.update(recon.get_seeds())
             return output.squeeze(), metadata
         return output, {}
+
+
+class SimulatedBoundaries(RandTransform):
+    """Skull-stripping boundary simulation: no masking, a halo around the brain mask, and / or fuzzy, locally
+    varying boundaries (ref :428-604).  Masks are float32 0/1 volumes here (int32 in the reference)."""
+
+    def __init__(self, prob_no_mask: float, prob_if_mask_halo: float, prob_if_mask_fuzzy: float):
+        self.prob_no_mask = prob_no_mask
+        self.prob_halo = prob_if_mask_halo
+        self.prob_fuzzy = prob_if_mask_fuzzy
+        self.reset_seeds()
+
+    def reset_seeds(self):
+        self.no_mask_on = None
+        self.halo_on = None
+        self.halo_radius = None
+        self.fuzzy_on = None
+        self.n_generate_fuzzy = None
+        self.n_centers = None
+        self.base_sigma = None
+
+    def sample_seeds(self):
+        """numpy draws: rand [, rand [, randint(5,15)], rand [, randint(2,5), poisson(100), poisson(8)]] (ref :468-482)."""
+        self.reset_seeds()
+        self.no_mask_on = np.random.rand() < self.prob_no_mask
+        if not self.no_mask_on:
+            self.halo_on = np.random.rand() < self.prob_halo
+            if self.halo_on:
+                self.halo_radius = np.random.randint(5, 15)
+            self.fuzzy_on = np.random.rand() < self.prob_fuzzy
+            if self.fuzzy_on:
+                self.n_generate_fuzzy = np.random.randint(2, 5)
+                self.n_centers = np.random.poisson(100)
+                self.base_sigma = np.random.poisson(8)
+
+    def build_halo(self, mask, radius) -> torch.Tensor:
+        """Dilation by a ball of `radius` (ref :484-499: conv3d with skimage's ball(radius), (2r+1)^3 taps): three
+        passes of a capped squared-distance transform and a threshold."""
+        m = mask.reshape(mask.shape[-3:]).float().contiguous()
+        r = int(radius)
+        return K.less_equal(K.distance_to_mask(m, r, "euclid2"), float(r * r))
+
+    def generate_fuzzy_boundaries(self, mask, kernel_size=7, threshold_filter=3) -> torch.Tensor:
+        """Grow the mask by random blobs seeded in its 7-voxel shell, then close (ref :501-522).  The reference keeps a
+        random 10 % of the shell voxels through a randperm; in device-RNG mode each shell voxel is kept with p = 0.1."""
+        shape = mask.shape
+        m = mask.reshape(shape[-3:]).float().contiguous()
+        shell = K.sub_gt(K.threshold(K.box_sum3d(m, kernel_size), 0.0), m, 0.0)
+        if _rng.get_mode() == "reference":
+            count, select = K.nonzero_ranks(shell, "!=", 0.0)
+            kept = torch.randperm(count)[int(count * 0.9):]
+            diff = K.scatter_ones(m.shape, select(kept, flat_device=True), m.device)
+        else:
+            key = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+            diff = K.bernoulli_keep(shell, 0.1, key, stream_id=9)
+        dsamp = K.threshold(K.box_sum3d(diff, 3), float(threshold_filter))
+        grown = K.threshold(K.box_sum3d(K.maximum(m, dsamp), 5), 0.0)       # dilate(.., 5)
+        closing = K.equals(K.box_sum3d(grown, 5), float(5**3))              # erode(.., 5)
+        return closing.view(shape)
+
+    def __call__(self, output, seg, device, genparams: dict = {}, **kwargs):
+        self.sample_seeds()
+        metadata = {"no_mask_on": self.no_mask_on, "halo_on": self.halo_on, "fuzzy_on": self.fuzzy_on}
+        if self.no_mask_on:
+            return output, metadata
+        _need_gpu(output)
+        out = output.float().contiguous()
+        mask = K.threshold(seg.to(out.device).float().contiguous(), 0.0)
+        if self.halo_on:
+            mask = self.build_halo(mask, self.halo_radius)
+        if self.fuzzy_on:
+            mask_modif = mask
+            for _ in range(self.n_generate_fuzzy):
+                mask_modif = self.generate_fuzzy_boundaries(mask_modif)
+            # centres of the probability blobs: random voxels among those the fuzzy growth added (ref :565-574)
+            count, select = K.nonzero_ranks(K.sub_gt(mask_modif, mask, 0.0), ">", 0.0)
+            centers = select(torch.randperm(count)[: self.n_centers])
+            sigmas = [self.base_sigma + 10 * np.random.beta(2, 5) for _ in range(len(centers))]
+            if len(centers):
+                mog = K.mog3d(mask.shape, *mog_params([tuple(v) for v in centers.tolist()], sigmas), out.device)
+            else:
+                mog = torch.zeros_like(mask)
+            n_dilate = 6 * (self.n_generate_fuzzy - 1)
+            dist = K.distance_to_mask(mask, n_dilate, "l1")
+            return K.boundary_mask(out, mask, mask_modif, mog, dist, n_dilate), metadata
+        return K.mul(out, mask), metadata

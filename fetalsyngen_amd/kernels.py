@@ -667,10 +667,11 @@ def nonzero_ranks(vol, op=">", value=0.0):
     total = int(ends[-1]) if nb else 0
     shape = tuple(vol.shape)
 
-    def select(ranks):
+    def select(ranks, flat_device=False):
         r = np.asarray(ranks, dtype=np.int64).reshape(-1)
         if r.size == 0:
-            return torch.zeros((0, len(shape)), dtype=torch.int64)
+            return torch.zeros((0,) if flat_device else (0, len(shape)), dtype=torch.int64,
+                               device=vol.device if flat_device else "cpu")
         if r.min() < 0 or r.max() >= total:
             raise IndexError("rank out of range")
         b = np.searchsorted(ends, r, side="right")
@@ -680,6 +681,8 @@ def nonzero_ranks(vol, op=">", value=0.0):
         out = torch.empty(r.size, dtype=torch.int64, device=vol.device)
         _lib.check(sel_fn(_p(vol), n, mode, float(value), _p(d[0]), _p(d[1]), int(r.size), _p(out), _stream(vol)),
                    "fsg_nonzero_select")
+        if flat_device:
+            return out
         flat = out.cpu().numpy()
         if (flat < 0).any():
             raise RuntimeError("nonzero_select: volume changed between count and select")
@@ -720,7 +723,7 @@ def compact_values(values, pred, op=">", value=0.0):
     return out
 
 
-_EWISE = {"add": 0, "gt": 1, "eq": 2, "mul": 3, "mul_gt": 4}
+_EWISE = {"add": 0, "gt": 1, "eq": 2, "mul": 3, "mul_gt": 4, "max": 5, "sub_gt": 6, "le": 7}
 
 
 def _ewise(op, a, b=None, value=0.0):
@@ -755,3 +758,63 @@ def mul(a, b):
 def mask_mul(a, b, value=0.0):
     """a * (b > value)."""
     return _ewise("mul_gt", a, b, value)
+
+
+def maximum(a, b):
+    return _ewise("max", a, b)
+
+
+def sub_gt(a, b, value=0.0):
+    """((a - b) > value) as float32 0/1."""
+    return _ewise("sub_gt", a, b, value)
+
+
+def less_equal(a, value):
+    return _ewise("le", a, None, value)
+
+
+def distance_to_mask(mask, radius: int, metric: str) -> torch.Tensor:
+    """Capped distance transform of a float 0/1 mask: squared Euclidean ("euclid2", exact where <= radius^2) or
+    city block ("l1", exact where <= radius); three axis passes of fsg_dist_pass_f32."""
+    _need_gpu(mask)
+    n0, n1, n2 = _dims3(_f32(mask, "mask"))
+    m = {"euclid2": 0, "l1": 1}[metric]
+    lib, st = _lib.load(), _stream(mask)
+    src, first = mask, 1
+    for axis in (2, 1, 0):
+        dst = torch.empty_like(mask)
+        _lib.check(lib.fsg_dist_pass_f32(_p(src), _p(dst), n0, n1, n2, axis, int(radius), m, first, st), "fsg_dist_pass_f32")
+        src, first = dst, 0
+    return src
+
+
+def boundary_mask(image, mask, mask_modif, mog, dist, n_dilate: int, want_mask=False):
+    _need_gpu(image, mask, mask_modif, mog, dist)
+    n = int(mask.numel())
+    for t_ in (image, mask, mask_modif, mog, dist):
+        if t_ is not None and (_f32(t_).numel() != n):
+            raise ValueError("boundary_mask operands must have one size")
+    out = torch.empty_like(mask) if image is not None else None
+    mo = torch.empty_like(mask) if want_mask else None
+    rc = _lib.load().fsg_boundary_mask_f32(_p(image), _p(mask), _p(mask_modif), _p(mog), _p(dist), int(n_dilate), n, _p(out),
+                                           _p(mo), _stream(mask))
+    _lib.check(rc, "fsg_boundary_mask_f32")
+    return (out, mo) if want_mask else out
+
+
+def bernoulli_keep(a, p: float, seed: int, stream_id: int = 0):
+    _need_gpu(a)
+    out = torch.empty_like(_f32(a))
+    _lib.check(_lib.load().fsg_bernoulli_keep_f32(_p(a), a.numel(), float(p), int(seed), int(stream_id), _p(out), _stream(a)),
+               "fsg_bernoulli_keep_f32")
+    return out
+
+
+def scatter_ones(shape, flat_idx, device):
+    """Zero float volume of `shape` with ones at the flat (int64, device) indices."""
+    _need_gpu(flat_idx)
+    out = torch.zeros(tuple(shape), dtype=F32, device=device)
+    if flat_idx.numel():
+        _lib.check(_lib.load().fsg_scatter_const_f32(_p(out), _p(flat_idx.contiguous()), int(flat_idx.numel()), 1.0,
+                                                     _stream(out)), "fsg_scatter_const_f32")
+    return out

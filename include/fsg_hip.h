@@ -307,8 +307,25 @@ int fsg_nonzero_select_u8(const uint8_t* v, size_t n, int mode, float value, con
 int fsg_compact_f32(const float* values, const float* pred, size_t n, int mode, float value, const long long* offsets,
                     float* out, void* stream);
 /* Element-wise glue of the artifact stages.  op 0: a + b; 1: (a > value) as 0/1; 2: (a == value) as 0/1; 3: a * b;
- * 4: a * (b > value).  b may be NULL for ops 1 and 2. */
+ * 4: a * (b > value); 5: max(a, b); 6: ((a - b) > value) as 0/1; 7: (a <= value) as 0/1.  b may be NULL for ops 1, 2, 7. */
 int fsg_ewise_f32(const float* a, const float* b, size_t n, int op, float value, float* out, void* stream);
+
+/* One axis pass of a capped distance transform: dst[v] = min over |t| <= radius (inside the volume) of
+ * src'[v + t e_axis] + cost(t), cost = t^2 (metric 0) or |t| (metric 1); first != 0: src is a mask (set -> 0, else 1e9).
+ * Passes over axes 0,1,2 give the squared Euclidean / city-block distance to the mask where it is <= radius^2 / radius:
+ * `dist <= radius^2` is the reference's zero-padded conv3d with skimage's ball(radius) > 0 (augmentation/artifacts.py:484-499)
+ * without its (2r+1)^3 taps; `city-block dist <= k` is k successive ball(1) dilations (artifacts.py:587-589).  src != dst. */
+int fsg_dist_pass_f32(const float* src, float* dst, int n0, int n1, int n2, int axis, int radius, int metric, int first,
+                      void* stream);
+/* SimulatedBoundaries' fuzzy mask (augmentation/artifacts.py:565-604) fused: k = clamp(rint(p n_dilate - 1), 0) with
+ * p = mog where mask_modif added voxels to mask (0 elsewhere); m = mask_modif * (dist <= max(k-1, 0)), dist = city-block
+ * distance to mask; out = image * m (out/image may be NULL), mask_out = m (may be NULL). */
+int fsg_boundary_mask_f32(const float* image, const float* mask, const float* mask_modif, const float* mog, const float* dist,
+                          int n_dilate, size_t n, float* out, float* mask_out, void* stream);
+/* out = a * (u < p), u ~ U[0,1) from Philox(seed, stream_id) per element: device-RNG thinning of a voxel set. */
+int fsg_bernoulli_keep_f32(const float* a, size_t n, float p, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* out[idx[q]] = value for q < k (idx DEVICE int64, negative entries skipped). */
+int fsg_scatter_const_f32(float* out, const long long* idx, int k, float value, void* stream);
 
 /* ---- whole-sample launch sequence -------------------------------------------------------------------------- */
 /* One call = the fused kernel sequence of FetalSynthGen.sample (generator/model.py:231-276) for the

