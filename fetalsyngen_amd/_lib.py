@@ -128,6 +128,7 @@ SIGNATURES = {
     "fsg_slice_acq_forward_f32": [P, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, I, P],
     "fsg_slice_acq_adjoint_f32": [P, P, I, I, I, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "fsg_equalize_f32": [P, P, P, F, SZ, P],
+    "fsg_slice_acq_set_tuning": [I, I, I],
     "fsg_mog3d_f32": [P, P, I, I, I, I, P, P, P],
     "fsg_perlin_fractal_f32": [P, P, P, P, I, I, I, I, P, P, P],
     "fsg_blend_f32": [P, P, P, SZ, I, P, F, P, I, P, P, F, P, P, P],

@@ -15,6 +15,11 @@
 // (uniform reads are broadcasts; the interp_psf branch gathers its 2x2x2 neighbourhood from there).
 #include "fsg_common.h"
 
+int g_sa_cap = 3072;        // LDS accumulator cells (value + weight)
+int g_sa_zc = 3;            // PSF planes per accumulation chunk
+int g_sa_t16_extent = 20;   // use 16x16 tiles while pitch*15 + PSF width <= this
+int g_sa_auto = 1;          // derive planes-per-chunk (and a larger capacity if needed) from pitch and PSF size
+
 namespace {
 
 struct SaParams {
@@ -274,6 +279,223 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_adjoint_kernel(SaParams P
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// adjoint, interp_psf = true, with on-chip pre-summation.
+//
+// The scatter form issues two fp32 atomics per (pixel, tap): 7e9 of them for a 200-slice reconstruction at
+// 384^3, and global float atomics execute memory-side at a fixed byte rate (MI355X_MICROARCH.md, "Global float
+// atomics": ~1.3 TB/s for well-shaped wave instructions, 17x less for 64 lanes in 64 rows) -- the direct kernel
+// above spends 3/4 of its time there.  A tile of neighbouring pixels revisits the same voxels many times (taps
+// are 1 voxel apart, pixels 0.5-2 voxels apart), so this kernel sums a tile's contributions in LDS first:
+//   * workgroup = T x T pixel tile of one slice (T = 16: one pixel per thread; T = 8: wave g of the workgroup
+//     takes the PSF rows ky = g mod 4 of every pixel of the tile);
+//   * the PSF is walked in chunks of `zc` planes; per chunk the axis-aligned bounding box of the voxels the
+//     tile can reach is derived from the slice transform; if it fits the LDS accumulator (`cap` cells for
+//     value and weight) contributions go to LDS with ds_add_f32, and the box is flushed with one global
+//     atomic per touched cell in row order (contiguous x runs); otherwise the chunk falls back to direct
+//     global atomics.  A cell index outside the box (cannot happen by construction) also falls back.
+// Same sums as the direct kernel up to fp32 summation order (which is nondeterministic there as well).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sa_psf_at_fast(const SaLds& L, const SaParams& P, const float* __restrict__ T, float dx,
+                                               float dy, float dz, float& val) {
+  // float adds: fl32(fl64(a + b)) == fl32(a + b) for fp32 a, b (53 >= 2*24 + 2), so no double is needed here
+  const float xp = (T[0] * dx + T[4] * dy + T[8] * dz) + (float)(P.pw - 1) * 0.5f;
+  const float yp = (T[1] * dx + T[5] * dy + T[9] * dz) + (float)(P.ph - 1) * 0.5f;
+  const float zp = (T[2] * dx + T[6] * dy + T[10] * dz) + (float)(P.pd - 1) * 0.5f;
+  if (xp < 0 || yp < 0 || zp < 0 || xp >= (float)(P.pw - 1) || yp >= (float)(P.ph - 1) || zp >= (float)(P.pd - 1))
+    return false;
+  const float xf = floorf(xp), yf = floorf(yp), zf = floorf(zp);
+  const float wx = xp - xf, wy = yp - yf, wz = zp - zf;
+  const int sy = P.pw, sz = P.pw * P.ph;
+  const float* q = L.psf + (int)zf * sz + (int)yf * sy + (int)xf;
+  const float a00 = q[0] + wx * (q[1] - q[0]), a10 = q[sy] + wx * (q[sy + 1] - q[sy]);
+  const float a01 = q[sz] + wx * (q[sz + 1] - q[sz]), a11 = q[sz + sy] + wx * (q[sz + sy + 1] - q[sz + sy]);
+  const float b0 = a00 + wy * (a10 - a00), b1 = a01 + wy * (a11 - a01);
+  val = b0 + wz * (b1 - b0);
+  return true;
+}
+
+template <int T_, bool VM>
+__global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, const float* __restrict__ slices,
+                                                                float* __restrict__ vol, float* __restrict__ vol_weight,
+                                                                int zc, int cap) {
+  constexpr int NPIX = T_ * T_, G = 256 / NPIX;
+  extern __shared__ float smem[];
+  const int in = blockIdx.z;
+  const float* __restrict__ T = P.tr + (size_t)in * 12;
+  const SaLds L = sa_lds_layout(smem, P);
+  float* part = L.tz + 3 * P.pd;  // [256] partial pixel weights
+  float* accv = part + 256;
+  float* accw = accv + cap;
+  {
+    // sa_fill_lds with a 256-thread linear id
+    const int tid = threadIdx.x, np = P.pd * P.ph * P.pw;
+    for (int e = tid; e < np; e += 256) L.psf[e] = P.psf[e];
+    for (int e = tid; e < 3 * P.pw; e += 256) { const int a = e / P.pw, i = e - a * P.pw; L.tx[e] = T[a * 4 + 0] * (float)(i - P.pw / 2); }
+    for (int e = tid; e < 3 * P.ph; e += 256) { const int a = e / P.ph, i = e - a * P.ph; L.ty[e] = T[a * 4 + 1] * (float)(i - P.ph / 2); }
+    for (int e = tid; e < 3 * P.pd; e += 256) { const int a = e / P.pd, i = e - a * P.pd; L.tz[e] = T[a * 4 + 2] * (float)(i - P.pd / 2); }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int p = tid % NPIX, g = tid / NPIX;
+  const int ix0 = blockIdx.x * T_, iy0 = blockIdx.y * T_;
+  const int ix = ix0 + p % T_, iy = iy0 + p / T_;
+  bool live = ix < P.w && iy < P.h;
+  const size_t idx = ((size_t)(P.sid ? P.sid[in] : in) * P.h + (live ? iy : 0)) * P.w + (live ? ix : 0);
+  if (live && P.smask && !P.smask[idx]) live = false;
+  const float s = live ? slices[idx] : 0.f;
+  float xc, yc, zc_;
+  sa_centre(P, T, ix, iy, xc, yc, zc_);
+  const int Sy = P.W, Sz = P.H * P.W;
+  const float hx = (float)(P.W - 1), hy = (float)(P.H - 1), hz = (float)(P.D - 1);
+
+  // pass 1: pixel weight (slice_acq_cuda_kernel.cu:515-560), PSF rows split over the G waves of a pixel
+  float wsum = 0.f;
+  if (live) {
+    for (int kz = 0; kz < P.pd; ++kz) {
+      const float zx = L.tz[kz], zy = L.tz[P.pd + kz], zz = L.tz[2 * P.pd + kz];
+      for (int ky = g; ky < P.ph; ky += G) {
+        const float yx = L.ty[ky], yy = L.ty[P.ph + ky], yz = L.ty[2 * P.ph + ky];
+        const int ip0 = (kz * P.ph + ky) * P.pw;
+        for (int kx = 0; kx < P.pw; ++kx) {
+          float pv = L.psf[ip0 + kx];
+          if (pv == 0.f) continue;
+          const float x = xc + L.tx[kx] + yx + zx;
+          const float y = yc + L.tx[P.pw + kx] + yy + zy;
+          const float z = zc_ + L.tx[2 * P.pw + kx] + yz + zz;
+          if (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz) continue;
+          if (!sa_psf_at_fast(L, P, T, roundf(x) - xc, roundf(y) - yc, roundf(z) - zc_, pv)) continue;
+          wsum += pv;
+        }
+      }
+    }
+  }
+  if (G > 1) {
+    part[tid] = wsum;
+    __syncthreads();
+    wsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < G; ++q) wsum += part[q * NPIX + p];
+  }
+  if (wsum < 0.5f) live = false;
+  const float inv = live ? 1.f / wsum : 0.f;
+
+  // tile extent in slice coordinates (same for every chunk)
+  const int ixl = ix0, ixh = min(ix0 + T_ - 1, P.w - 1), iyl = iy0, iyh = min(iy0 + T_ - 1, P.h - 1);
+  const float alo = ((float)ixl - (float)(P.w - 1) * 0.5f) * P.res + T[3] - (float)(P.pw / 2);
+  const float ahi = ((float)ixh - (float)(P.w - 1) * 0.5f) * P.res + T[3] + (float)(P.pw - 1 - P.pw / 2);
+  const float blo = ((float)iyl - (float)(P.h - 1) * 0.5f) * P.res + T[7] - (float)(P.ph / 2);
+  const float bhi = ((float)iyh - (float)(P.h - 1) * 0.5f) * P.res + T[7] + (float)(P.ph - 1 - P.ph / 2);
+
+  // LDS cell layout: a chunk of PSF planes of a pixel tile is an oblique plate in the volume, whose axis-aligned
+  // bounding box can hold 10x more cells than the plate.  Cells are therefore indexed by the two volume axes (u, v)
+  // other than the one the slice normal leans on most (a), plus the offset k of the a-coordinate from the plate's
+  // mid-plane at (u, v): K = plate thickness along a, a few cells.  x is kept the fastest index for the flush.
+  const float n0 = T[2], n1 = T[6], n2 = T[10];  // slice normal in volume axes (x, y, z)
+  const int A = (fabsf(n0) >= fabsf(n1) && fabsf(n0) >= fabsf(n2)) ? 0 : (fabsf(n1) >= fabsf(n2) ? 1 : 2);
+  const int U = A == 0 ? 1 : 0, V = A == 2 ? 1 : 2;  // U < V, so x is U whenever x is not the lean axis
+  const float nA = A == 0 ? n0 : (A == 1 ? n1 : n2), nU = U == 0 ? n0 : n1, nV = V == 1 ? n1 : n2;
+  const float inv_na = 1.f / nA, slope = (fabsf(nU) + fabsf(nV)) * fabsf(inv_na);
+  const int dimv[3] = {P.W, P.H, P.D};
+  // tile centre in slice coordinates -> a point of the mid-plane (per chunk: its z)
+  const float amid = 0.5f * (alo + ahi), bmid = 0.5f * (blo + bhi);
+
+  for (int kz0 = 0; kz0 < P.pd; kz0 += zc) {
+    const int kz1 = min(kz0 + zc, P.pd);
+    const float clo = T[11] + (float)(kz0 - P.pd / 2), chi = T[11] + (float)(kz1 - 1 - P.pd / 2);
+    int o[3], b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float r0 = T[a * 4], r1 = T[a * 4 + 1], r2 = T[a * 4 + 2];
+      const float off = (float)(dimv[a] - 1) * 0.5f;
+      const float mn = off + fminf(r0 * alo, r0 * ahi) + fminf(r1 * blo, r1 * bhi) + fminf(r2 * clo, r2 * chi);
+      const float mx = off + fmaxf(r0 * alo, r0 * ahi) + fmaxf(r1 * blo, r1 * bhi) + fmaxf(r2 * clo, r2 * chi);
+      // voxel = round(position): [floor(mn + .5), floor(mx + .5)], widened by the fp32 slack of the position sums
+      const int lo = max((int)floorf(mn + 0.5f - 2e-3f), 0), hi = min((int)floorf(mx + 0.5f + 2e-3f), dimv[a] - 1);
+      o[a] = lo;
+      b[a] = hi - lo + 1;
+    }
+    if (b[0] <= 0 || b[1] <= 0 || b[2] <= 0) continue;  // the chunk cannot reach the volume (uniform)
+    const float cmid = 0.5f * (clo + chi);
+    float pm[3];  // mid-plane point in volume coordinates
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      pm[a] = (float)(dimv[a] - 1) * 0.5f + T[a * 4] * amid + T[a * 4 + 1] * bmid + T[a * 4 + 2] * cmid;
+    // thickness of the plate along A: PSF planes (kz1-1-kz0) / |nA|, voxel rounding 1 + slope, plus one cell of slack
+    const int K = (int)ceilf(((float)(kz1 - 1 - kz0) + 1.f) * fabsf(inv_na) + slope + 1.f) + 1;
+    const float hb = 0.5f * (float)K;
+    const int bu = b[U], bv = b[V];
+    const long long cells = (long long)bu * bv * K;
+    const bool use_lds = cells <= (long long)cap;
+    // index = ((cv * K + k) * bu + cu) when x is U (x fastest); = ((cv * bu + cu) * K + k) when x is the lean axis
+    const bool xlean = A == 0;
+    if (use_lds) {
+      for (int c = tid; c < (int)cells; c += 256) { accv[c] = 0.f; accw[c] = 0.f; }
+      __syncthreads();
+    }
+    if (live) {
+      for (int kz = kz0; kz < kz1; ++kz) {
+        const float zx = L.tz[kz], zy = L.tz[P.pd + kz], zz = L.tz[2 * P.pd + kz];
+        for (int ky = g; ky < P.ph; ky += G) {
+          const float yx = L.ty[ky], yy = L.ty[P.ph + ky], yz = L.ty[2 * P.ph + ky];
+          const int ip0 = (kz * P.ph + ky) * P.pw;
+          for (int kx = 0; kx < P.pw; ++kx) {
+            float pv = L.psf[ip0 + kx];
+            if (pv == 0.f) continue;
+            const float x = xc + L.tx[kx] + yx + zx;
+            const float y = yc + L.tx[P.pw + kx] + yy + zy;
+            const float z = zc_ + L.tx[2 * P.pw + kx] + yz + zz;
+            if (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz) continue;
+            const float xr = roundf(x), yr = roundf(y), zr = roundf(z);
+            if (!sa_psf_at_fast(L, P, T, xr - xc, yr - yc, zr - zc_, pv)) continue;
+            pv *= inv;
+            const int vv[3] = {(int)xr, (int)yr, (int)zr};
+            const int iv = vv[2] * Sz + vv[1] * Sy + vv[0];
+            if (VM && !P.vmask[iv]) continue;
+            bool done = false;
+            if (use_lds) {
+              const int cu = vv[U] - o[U], cv = vv[V] - o[V];
+              const float fu = (float)vv[U] - pm[U], fv = (float)vv[V] - pm[V];
+              const int base = (int)floorf(pm[A] - (nU * fu + nV * fv) * inv_na - hb);
+              const int k = vv[A] - base;
+              if ((unsigned)cu < (unsigned)bu && (unsigned)cv < (unsigned)bv && (unsigned)k < (unsigned)K) {
+                const int c = xlean ? (cv * bu + cu) * K + k : (cv * K + k) * bu + cu;
+                atomicAdd(&accv[c], pv * s);
+                atomicAdd(&accw[c], pv);
+                done = true;
+              }
+            }
+            if (!done) {
+              unsafeAtomicAdd(vol + iv, pv * s);
+              if (vol_weight) unsafeAtomicAdd(vol_weight + iv, pv);
+            }
+          }
+        }
+      }
+    }
+    if (use_lds) {
+      __syncthreads();
+      for (int c = tid; c < (int)cells; c += 256) {
+        const float wv = accw[c];
+        if (wv == 0.f) continue;
+        int cu, cv, k;
+        if (xlean) { k = c % K; const int r = c / K; cu = r % bu; cv = r / bu; }
+        else { cu = c % bu; const int r = c / bu; k = r % K; cv = r / K; }
+        int vv[3];
+        vv[U] = cu + o[U];
+        vv[V] = cv + o[V];
+        const float fu = (float)vv[U] - pm[U], fv = (float)vv[V] - pm[V];
+        vv[A] = (int)floorf(pm[A] - (nU * fu + nV * fv) * inv_na - hb) + k;
+        const int iv = vv[2] * Sz + vv[1] * Sy + vv[0];
+        unsafeAtomicAdd(vol + iv, accv[c]);
+        if (vol_weight) unsafeAtomicAdd(vol_weight + iv, wv);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // torch-fallback semantics (slice_acq.py:272-310): position = (shift + R((off - T) + T)) + R(pixel + T),
 // strict inside test, round half to even, raw PSF value; one kernel serves forward and adjoint.
@@ -458,11 +680,48 @@ int fsg_slice_acq_adjoint_f32(const float* transforms, const float* psf, int pd,
   } else if (mode == FSG_SA_LINEAR) {
     if (vol_mask) hipLaunchKernelGGL((sa_adjoint_kernel<false, true>), grid, block, lds, st, P, slices, vol, vol_weight);
     else hipLaunchKernelGGL((sa_adjoint_kernel<false, false>), grid, block, lds, st, P, slices, vol, vol_weight);
-  } else {
+  } else if (g_tuning_flags & FSG_TUNE_SA_DIRECT) {
     if (vol_mask) hipLaunchKernelGGL((sa_adjoint_kernel<true, true>), grid, block, lds, st, P, slices, vol, vol_weight);
     else hipLaunchKernelGGL((sa_adjoint_kernel<true, false>), grid, block, lds, st, P, slices, vol, vol_weight);
+  } else {
+    // tile: 16x16 pixels when their footprint (pixel pitch * 15 + PSF width) stays small, else 8x8; PSF planes per
+    // chunk and accumulator size from the expected cell count of a chunk's plate, E^2 * K inflated for a typical
+    // oblique orientation (each workgroup still decides per chunk whether ITS plate fits; if not it scatters directly)
+    const int ext = pw > ph ? pw : ph;
+    const bool t16 = res_slice * 15.f + (float)ext <= (float)g_sa_t16_extent;
+    const int tile = t16 ? 16 : 8;
+    const float E = res_slice * (float)(tile - 1) + (float)ext + 1.f;
+    auto est = [&](int z) { return 1.6f * E * E * (1.5f * (float)z + 3.f); };
+    int cap = g_sa_cap, zc = g_sa_zc < pd ? g_sa_zc : pd;
+    if (g_sa_auto) {
+      zc = 1;
+      for (int z = 4; z >= 1; --z)
+        if (est(z) <= (float)g_sa_cap) { zc = z; break; }
+      if (est(zc) > (float)cap) cap = (int)fminf(est(zc) * 1.25f, 12288.f);
+      if (zc > pd) zc = pd;
+    }
+    const size_t lds2 = lds + (256 + 2 * (size_t)cap) * sizeof(float);
+    const dim3 grid2((unsigned)((w + tile - 1) / tile), (unsigned)((h + tile - 1) / tile), (unsigned)n);
+#define SA_LAUNCH_LDS(TT, VMM)                                                                                         \
+  do {                                                                                                                \
+    auto kfn = sa_adjoint_nn_lds_kernel<TT, VMM>;                                                                     \
+    hipError_t ea = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);     \
+    if (ea != hipSuccess) return (int)ea;                                                                             \
+    hipLaunchKernelGGL(kfn, grid2, dim3(256), lds2, st, P, slices, vol, vol_weight, zc, cap);                         \
+  } while (0)
+    if (t16) { if (vol_mask) SA_LAUNCH_LDS(16, true); else SA_LAUNCH_LDS(16, false); }
+    else { if (vol_mask) SA_LAUNCH_LDS(8, true); else SA_LAUNCH_LDS(8, false); }
+#undef SA_LAUNCH_LDS
   }
   FSG_RETURN_LAUNCH();
+}
+
+int fsg_slice_acq_set_tuning(int cap_cells, int z_chunk, int t16_extent) {
+  if (cap_cells < 256 || cap_cells > 18432 || z_chunk < 0 || t16_extent < 0) return FSG_E_BADARG;
+  g_sa_cap = cap_cells; g_sa_zc = z_chunk; g_sa_t16_extent = t16_extent;
+  g_sa_auto = z_chunk == 0;
+  if (g_sa_auto) g_sa_zc = 3;
+  return 0;
 }
 
 int fsg_equalize_f32(float* vol, const float* vol_weight, const uint8_t* vol_mask, float threshold, size_t n, void* stream) {

@@ -73,6 +73,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
 #define FSG_TUNE_NO_PATCH 32     /* row kernel (4 waves, own rows) instead of the 16-wave lockstep patch kernel */
 #define FSG_TUNE_BUFFER_LOADS 64 /* opt in: patch kernel body on raw buffer loads (fewer instructions, slower in r01) */
+#define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
 
@@ -249,6 +250,11 @@ int fsg_slice_acq_adjoint_f32(const float* transforms, const float* psf, int pd,
                               const uint8_t* slices_mask, const int32_t* slice_ids, const uint8_t* vol_mask, float* vol,
                               float* vol_weight, int D, int H, int W, int n, int h, int w, float res_slice, int mode,
                               void* stream);
+/* Shape of the LDS pre-summation of the FSG_SA_NEAREST_PSF adjoint: accumulator cells (value + weight, 8 B each,
+ * 256..18432), PSF planes per chunk, and the footprint (pixel pitch * 15 + PSF width, voxels) up to which 16x16-pixel
+ * tiles are used instead of 8x8.  z_chunk 0 (default) derives the planes per chunk, and a larger capacity when one
+ * plane does not fit, from the pixel pitch and the PSF size.  Defaults 3072 / 0 / 20.  Results do not depend on it beyond fp32 summation order. */
+int fsg_slice_acq_set_tuning(int cap_cells, int z_chunk, int t16_extent);
 /* vol[i] /= vol_weight[i] where vol_weight[i] > threshold (0 for the CUDA kernel :681-691, 1e-2 for the
  * fallback slice_acq.py:542-543); then vol[i] *= vol_mask[i] if vol_mask (fallback :544-545).  Either of
  * vol_weight / vol_mask may be NULL, not both. */

@@ -140,3 +140,35 @@ def test_adjoint_slice_subset_without_copy(K, golden):
     b = K.slice_acq_adjoint(tr[keep.to(DEV)].contiguous(), psf, s, None, None, VS, RES, interp_psf=True, equalize=True,
                             slice_ids=keep.to(torch.int32).to(DEV))
     np.testing.assert_allclose(host(a), host(b), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("tuning", [(4096, 0, 20), (4096, 3, 20), (8192, 6, 20), (512, 1, 0), (2048, 2, 0), (16384, 64, 1000)])
+def test_adjoint_lds_presum_matches_direct_atomics(K, tuning):
+    """The interp_psf adjoint sums a pixel tile's contributions in LDS before touching HBM (chunked PSF planes, bounding
+    box per chunk, fallback to direct atomics when the box does not fit): same result as the direct-atomics kernel for
+    any tile shape / capacity, at sizes where both the LDS path and the fallback are exercised."""
+    from fetalsyngen_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    n, ss, vs = 12, 96, (72, 80, 88)
+    psf = dev(S.get_psf(res_ratio=(1.4, 1.4, 5.0)).numpy())
+    tr = _random_rigid(rng, n, 1.2, 12.0)
+    tr[:, 2, 3] += np.linspace(-20, 20, n, dtype=np.float32)
+    s = torch.rand((n, ss, ss), device=DEV)
+    sm = torch.rand((n, ss, ss), device=DEV) > 0.1
+    vm = torch.rand(vs, device=DEV) > 0.1
+    for masks in ((None, None), (sm, vm)):
+        prev = lib.fsg_set_tuning(128)  # FSG_TUNE_SA_DIRECT
+        try:
+            ref, refw = K.slice_acq_adjoint(dev(tr), psf, s, masks[0], masks[1], vs, 1.4, interp_psf=True, return_weight=True)
+        finally:
+            lib.fsg_set_tuning(prev)
+        assert lib.fsg_slice_acq_set_tuning(*tuning) == 0
+        try:
+            got, gotw = K.slice_acq_adjoint(dev(tr), psf, s, masks[0], masks[1], vs, 1.4, interp_psf=True, return_weight=True)
+        finally:
+            lib.fsg_slice_acq_set_tuning(3072, 0, 20)
+        assert float(refw.sum()) > 1000
+        np.testing.assert_allclose(host(gotw), host(refw), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(host(got), host(ref), rtol=1e-5, atol=2e-5)

@@ -223,3 +223,41 @@ def test_simulated_boundaries_vs_reference(env, golden, case, seed, ph, pf):
     assert ((got != 0) != (ref != 0)).mean() < 2e-4
     same = (got != 0) == (ref != 0)
     np.testing.assert_allclose(got[same], ref[same], atol=1e-6)
+
+
+# ---- BASELINE config 4: 384^3 with the SR-artifact slice-stack simulation -------------------------------------------
+def test_config4_384_with_sr_artifacts(env):
+    """Full default-YAML stage stack (BlurCortex, StructNoise, SimulateMotion, SimulatedBoundaries, every gate on) behind
+    FetalSynthGen at 384^3 / 0.5 mm, device RNG, CUDA-kernel slice-acquisition semantics.  No reference output exists at
+    this size (the CPU fallback would need hours): checked through properties."""
+    from fetalsyngen_amd import rng
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.generator.artifacts.svort import slice_acq as sa
+    from fetalsyngen_amd.phantom import make_seed_volumes
+    from tests.util_cases import default_artifacts, make_generator
+
+    shape = (384, 384, 384)
+    seg, seeds = make_seed_volumes(shape)
+    bank, segd = SeedBank(seeds, DEV), dev(seg.astype(np.float32))
+    prev_sem, prev_rng = sa.set_semantics("cuda"), rng.get_mode()
+    rng.set_mode("device")
+    try:
+        gen = make_generator(shape, DEV, rng="device", prob=1.0, artifacts=default_artifacts(prob=1.0))
+        np.random.seed(11)
+        torch.manual_seed(11)
+        out, lab, _, params = gen.sample(None, segd, bank, {})
+    finally:
+        sa.set_semantics(prev_sem)
+        rng.set_mode(prev_rng)
+    art = params["artifacts"]
+    assert set(art) == {"blur_cortex", "struct_noise", "simulate_motion", "boundaries"}
+    assert 50 <= art["blur_cortex"]["nblur"] < 200 and 1 <= art["struct_noise"]["nstages"] < 5
+    sm = art["simulate_motion"]
+    assert 2 <= sm["nstacks"] <= 6 and 0.25 <= sm["resolution_slice"] <= 1.0 and 1.5 <= sm["slice_thickness"] <= 3.5
+    assert tuple(out.shape) == shape and bool(torch.isfinite(out).all())
+    assert float(out.min()) >= 0.0 and 0.2 < float(out.max()) < 2.5
+    brain = lab > 0
+    # the reconstruction covers the brain: almost every brain voxel received signal, the far background none
+    assert float((out[brain] > 0).float().mean()) > 0.97
+    if art["boundaries"]["no_mask_on"] is False and not art["boundaries"]["halo_on"] and not art["boundaries"]["fuzzy_on"]:
+        assert float(out[~brain].abs().max()) == 0.0

@@ -60,6 +60,28 @@ def main():
         "forward_torch_ms": lambda: K.slice_acq_forward(tr, vol, None, None, psf, (ss, ss), rs, semantics="torch"),
     }.items():
         out[name] = round(timed(fn, a.reps), 3)
+    # adjoint (interp_psf + equalize): direct atomics vs LDS pre-summation under a few shapes, and vs stack tilt
+    from fetalsyngen_amd import _lib
+    lib = _lib.load()
+    adj = lambda t=tr: K.slice_acq_adjoint(t, psf, s, None, None, vs, rs, interp_psf=True, equalize=True)  # noqa: E731
+    prev = lib.fsg_set_tuning(128)
+    out["adjoint_direct_ms"] = round(timed(adj, a.reps), 3)
+    lib.fsg_set_tuning(prev)
+    sweep = {}
+    cfgs = ((4096, 0, 20), (3072, 0, 20), (6144, 0, 20), (4096, 3, 20), (4096, 2, 20), (6144, 1, 20), (4096, 0, 0), (4096, 0, 40))
+    for ang in (0.3, 0.8, 1.5):
+        np.random.seed(1)
+        t2 = random_stack(a.slices, gap=a.size * res / a.slices / res, max_angle=ang).to(dev)
+        row = {}
+        prev = lib.fsg_set_tuning(128)
+        row["direct"] = round(timed(lambda: adj(t2), a.reps), 2)
+        lib.fsg_set_tuning(prev)
+        for cap, zc, t16 in cfgs:
+            lib.fsg_slice_acq_set_tuning(cap, zc, t16)
+            row[f"{cap}/{zc}/{t16}"] = round(timed(lambda: adj(t2), a.reps), 2)
+        sweep[f"tilt{ang}"] = row
+    lib.fsg_slice_acq_set_tuning(3072, 0, 20)
+    out["adjoint_sweep_ms"] = sweep
     out["pixel_taps"] = npix * ntap
     out["forward_linear_Gtaps_per_s"] = round(npix * ntap / out["forward_linear_ms"] / 1e6, 2)
     out["adjoint_Gtaps_per_s"] = round(npix * ntap / out["adjoint_nearest_psf_eq_ms"] / 1e6, 2)
