@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void mog_tables_kernel(const float* __restrict
 }
 
 // out = clamp(sum_g exp(-(tx + ty + tz) / 2), 0, 1); one thread = 4 consecutive x
+template <bool FAST>
 __global__ __launch_bounds__(256) void mog_sum_kernel(const float* __restrict__ tab, int k, int D, int H, int W, int L,
                                                       float* __restrict__ out) {
   const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void mog_sum_kernel(const float* __restrict__ 
     for (int q = 0; q < 4; ++q) {
       if (x4 + q < W) {
         const float d = tx[x4 + q] + ty + tz;
-        acc[q] += expf(-d / 2);
+        acc[q] += FAST ? __builtin_amdgcn_exp2f(d * -0.72134752044448170368f) : expf(-d / 2);  // v_exp_f32
       }
     }
   }
@@ -388,8 +389,11 @@ int fsg_mog3d_f32(const float* centers, const float* sigmas, int k, int D, int H
   hipLaunchKernelGGL(mog_tables_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, centers, sigmas, k, D, H, W, L,
                      tables);
   const int tx = W >= 1024 ? 256 : 64;
-  hipLaunchKernelGGL(mog_sum_kernel, dim3((unsigned)((W + 4 * tx - 1) / (4 * tx)), (unsigned)H, (unsigned)D), dim3(tx), 0, st,
-                     (const float*)tables, k, D, H, W, L, out);
+  const dim3 grid((unsigned)((W + 4 * tx - 1) / (4 * tx)), (unsigned)H, (unsigned)D);
+  if (g_tuning_flags & FSG_TUNE_PRECISE_MATH)
+    hipLaunchKernelGGL(mog_sum_kernel<false>, grid, dim3(tx), 0, st, (const float*)tables, k, D, H, W, L, out);
+  else
+    hipLaunchKernelGGL(mog_sum_kernel<true>, grid, dim3(tx), 0, st, (const float*)tables, k, D, H, W, L, out);
   FSG_RETURN_LAUNCH();
 }
 

@@ -189,6 +189,106 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_kernel(SaParams P
   if (weights) weights[idx] = good ? weight : 0.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// forward, interp_psf = false, no volume mask: the acquisition of Scanner.scan (simulate_reco.py:386-396).
+// Same sampling positions as sa_forward_kernel; the 2x2x2 blend is evaluated as lerps on x-pairs fetched with one
+// 8-byte load each (4 loads and ~20 VALU per tap instead of 8 loads and ~55), and the weight sum uses that the eight
+// trilinear weights of a tap add up to its PSF value.  Differs from the operation order of the CUDA source by fp32
+// rounding only (1e-7 relative; nvcc contracts that source to FMAs anyway); FSG_TUNE_PRECISE_MATH selects
+// sa_forward_kernel instead.
+// ---------------------------------------------------------------------------------------------------------
+typedef float sa_f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// The per-tap work is a dependent chain (position -> address -> 2x2x2 gather -> blend), and the CUDA-ordered kernel
+// waits for each tap's gathers before starting the next tap: at 8 waves per SIMD it runs at gather latency, not at
+// throughput.  Here the taps with a non-zero PSF value are compacted once per workgroup into LDS as
+// (rotated offset, value) -- one ds_read_b128 per tap -- and walked four at a time with the bounds test turned into
+// a predicate (safe address, zero weight), so 16 independent 8-byte gathers are in flight per lane before the first
+// blend.  Waves whose pixels all lie farther from the volume than the PSF radius leave at once.
+__global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kernel(SaParams P, const float* __restrict__ vol,
+                                                                                  float* __restrict__ slices,
+                                                                                  float* __restrict__ weights) {
+  extern __shared__ float smem[];
+  const int in = blockIdx.z;
+  const float* __restrict__ T = P.tr + (size_t)in * 12;
+  const int np = P.pd * P.ph * P.pw;
+  float4* taps = reinterpret_cast<float4*>(smem);  // [<= np] (ox, oy, oz, psf)
+  __shared__ int ntaps_s;
+  const int tid = threadIdx.y * SA_TILE + threadIdx.x;
+  if (tid < 64) {  // wave 0: raster-order compaction by ballot prefix
+    int count = 0;
+    for (int base = 0; base < np; base += 64) {
+      const int e = base + tid;
+      const float pv = e < np ? P.psf[e] : 0.f;
+      const bool nz = pv != 0.f;
+      const unsigned long long bal = __ballot(nz);
+      if (nz) {
+        const int kx = e % P.pw, ky = (e / P.pw) % P.ph, kz = e / (P.pw * P.ph);
+        const float fx = (float)(kx - P.pw / 2), fy = (float)(ky - P.ph / 2), fz = (float)(kz - P.pd / 2);
+        taps[count + __popcll(bal & ((1ull << tid) - 1ull))] =
+            make_float4(T[0] * fx + T[1] * fy + T[2] * fz, T[4] * fx + T[5] * fy + T[6] * fz,
+                        T[8] * fx + T[9] * fy + T[10] * fz, pv);
+      }
+      count += __popcll(bal);
+    }
+    if (tid == 0) ntaps_s = count;
+  }
+  __syncthreads();
+  const int nt = ntaps_s;
+  const int ix = blockIdx.x * SA_TILE + threadIdx.x, iy = blockIdx.y * SA_TILE + threadIdx.y;
+  const bool inside = ix < P.w && iy < P.h;
+  const size_t idx = ((size_t)in * P.h + (inside ? iy : 0)) * P.w + (inside ? ix : 0);
+  bool live = inside && !(P.smask && !P.smask[idx]);
+  float xc, yc, zc;
+  sa_centre(P, T, ix, iy, xc, yc, zc);
+  const float hx = (float)(P.W - 1), hy = (float)(P.H - 1), hz = (float)(P.D - 1);
+  const float rad = 0.5f * sqrtf((float)(P.pw * P.pw + P.ph * P.ph + P.pd * P.pd)) + 1.f;
+  if (xc < -rad || yc < -rad || zc < -rad || xc > hx + rad || yc > hy + rad || zc > hz + rad) live = false;
+  float val = 0.f, weight = 0.f;
+  if (__any(live)) {
+    const int Sy = P.W, Sz = P.H * P.W;
+    for (int t = 0; t < nt; t += 4) {
+      float pvv[4], wxx[4], wyy[4], wzz[4];
+      const float* qq[4];
+      bool anyin = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 tp = taps[min(t + u, nt - 1)];
+        const float x = xc + tp.x, y = yc + tp.y, z = zc + tp.z;
+        const bool ok = live && (t + u < nt) && !(x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz);
+        const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+        wxx[u] = x - xf; wyy[u] = y - yf; wzz[u] = z - zf;
+        pvv[u] = ok ? tp.w : 0.f;
+        qq[u] = ok ? vol + ((int)zf * Sz + (int)yf * Sy + (int)xf) : vol;
+        anyin |= ok;
+      }
+      if (!__any(anyin)) continue;
+      sa_f2u p00[4], p10[4], p01[4], p11[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p00[u] = *reinterpret_cast<const sa_f2u*>(qq[u]);
+        p10[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sy);
+        p01[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sz);
+        p11[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sz + Sy);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float wx = wxx[u], wy = wyy[u], wz = wzz[u];
+        const float a00 = p00[u].x + wx * (p00[u].y - p00[u].x), a10 = p10[u].x + wx * (p10[u].y - p10[u].x);
+        const float a01 = p01[u].x + wx * (p01[u].y - p01[u].x), a11 = p11[u].x + wx * (p11[u].y - p11[u].x);
+        const float b0 = a00 + wy * (a10 - a00), b1 = a01 + wy * (a11 - a01);
+        val += pvv[u] * (b0 + wz * (b1 - b0));
+        weight += pvv[u];
+      }
+    }
+  }
+  if (!inside) return;
+  const bool good = weight > 0.f;
+  slices[idx] = good ? val / weight : 0.f;
+  if (weights) weights[idx] = good ? weight : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // adjoint, CUDA-kernel semantics (:472-670): pass 1 = pixel weight, pass 2 = scatter with fp32 atomics.
 // ---------------------------------------------------------------------------------------------------------
@@ -647,7 +747,10 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
                          (float*)nullptr);
   } else if (mode == FSG_SA_LINEAR) {
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<false, true>), grid, block, lds, st, P, vol, slices, slices_weight);
-    else hipLaunchKernelGGL((sa_forward_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight);
+    else if ((g_tuning_flags & FSG_TUNE_PRECISE_MATH) || pd * ph * pw > 4000)  // (the fast kernel keeps 16 B per tap in LDS)
+      hipLaunchKernelGGL((sa_forward_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight);
+    else hipLaunchKernelGGL(sa_forward_linear_fast_kernel, grid, block, (size_t)pd * ph * pw * 4 * sizeof(float), st, P, vol,
+                            slices, slices_weight);
   } else {
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<true, true>), grid, block, lds, st, P, vol, slices, slices_weight);
     else hipLaunchKernelGGL((sa_forward_kernel<true, false>), grid, block, lds, st, P, vol, slices, slices_weight);

@@ -363,7 +363,7 @@ class PSFReconstructor:
         """`_ngaussians_merge` distinct voxels of the mask, as the reference's randperm over them (ref :661-664)."""
         m = vol_mask.reshape(vol_mask.shape[-3:]).contiguous()  # bool mask, or the float label map itself (> 0)
         count, select = K.nonzero_ranks(m, ">", 0.0)
-        idx = torch.randperm(count)[: self._ngaussians_merge]
+        idx = _rng.distinct_ranks(count, self._ngaussians_merge)
         return select(idx)  # (k,3) int64 host, first-axis index first
 
     def get_merging_weights(self, shape, vol_mask=None):

@@ -67,7 +67,7 @@ class BlurCortex(RandTransform):
             std_blurs = np.random.gamma(self.std_blur_shape, self.std_blur_scale, 3)
             seg = seg.to(output.device).float().contiguous()
             cortex_prob = self.blur_proba(output.shape, seg, output.device)
-            idx = torch.multinomial(cortex_prob, nblur)  # CPU generator, as a CPU run of the reference
+            idx = _rng.multinomial_distinct(cortex_prob, nblur)  # CPU generator (torch.multinomial in reference mode)
             count, select = K.nonzero_ranks(seg, "==", float(self.cortex_label))
             centers = select(idx)
             sigmas = np.random.gamma(self.sigma_gamma_loc, self.sigma_gamma_scale, (nblur, 3))
@@ -132,7 +132,7 @@ class StructNoise(RandTransform):
         mp = self.merge_params
         if mp.merge_type == "gaussian":
             count, select = K.nonzero_ranks(seg, "==", float(self.wm_label))
-            centers = select(torch.randperm(count)[: self.gauss_nloc])
+            centers = select(_rng.distinct_ranks(count, self.gauss_nloc))
             sig = torch.clamp(mp.gauss_sigma_mu + mp.gauss_sigma_std * torch.randn(len(centers)), 1, 40).numpy()
             c, s = mog_params([tuple(v) for v in centers.tolist()], sig)
             return K.mog3d(shape, c, s, device), None
@@ -147,7 +147,7 @@ class StructNoise(RandTransform):
         matter mask (bool / uint8 / float)."""
         if self.merge_params.merge_type == "gaussian":
             count, select = K.nonzero_ranks(mask.reshape(mask.shape[-3:]).contiguous(), ">", 0.0)
-            centers = select(torch.randperm(count)[: self.gauss_nloc])
+            centers = select(_rng.distinct_ranks(count, self.gauss_nloc))
             mp = self.merge_params
             sig = torch.clamp(mp.gauss_sigma_mu + mp.gauss_sigma_std * torch.randn(len(centers)), 1, 40).numpy()
             return K.mog3d(shape, *mog_params([tuple(v) for v in centers.tolist()], sig), device)
@@ -300,7 +300,7 @@ class SimulatedBoundaries(RandTransform):
                 mask_modif = self.generate_fuzzy_boundaries(mask_modif)
             # centres of the probability blobs: random voxels among those the fuzzy growth added (ref :565-574)
             count, select = K.nonzero_ranks(K.sub_gt(mask_modif, mask, 0.0), ">", 0.0)
-            centers = select(torch.randperm(count)[: self.n_centers])
+            centers = select(_rng.distinct_ranks(count, self.n_centers))
             sigmas = [self.base_sigma + 10 * np.random.beta(2, 5) for _ in range(len(centers))]
             if len(centers):
                 mog = K.mog3d(mask.shape, *mog_params([tuple(v) for v in centers.tolist()], sigmas), out.device)

@@ -72,3 +72,45 @@ def normal_field(shape, stream_id: int = 0) -> Field:
         return Field(shape, host=torch.randn(tuple(shape), dtype=torch.float32))
     key = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
     return Field(shape, seed=key, stream_id=stream_id)
+
+
+def distinct_ranks(count: int, k: int) -> torch.Tensor:
+    """k distinct uniform integers in [0, count) (all of them, shuffled, if k >= count).
+
+    "reference": `torch.randperm(count)[:k]`, the reference's own draw (simulate_reco.py:662, artifacts.py:200, :566) --
+    O(count) host work, count = voxels of a mask.  "device": sequential draws with rejection of repeats from the same
+    CPU generator -- the same distribution, O(k) work."""
+    count, k = int(count), int(k)
+    if _MODE == "reference" or k >= count // 2:
+        return torch.randperm(count)[:k]
+    seen, out = set(), []
+    while len(out) < k:
+        for v in torch.randint(0, count, (2 * (k - len(out)) + 8,), dtype=torch.int64).tolist():
+            if v not in seen:
+                seen.add(v)
+                out.append(v)
+                if len(out) == k:
+                    break
+    return torch.tensor(out, dtype=torch.int64)
+
+
+def multinomial_distinct(prob: torch.Tensor, k: int) -> torch.Tensor:
+    """k distinct indices drawn sequentially with probability proportional to `prob` (host tensor, need not be normalised).
+
+    "reference": `torch.multinomial(prob, k)` (artifacts.py:110).  "device": inverse-CDF draws with rejection of repeats
+    (sequential sampling without replacement, the same distribution) -- one cumulative sum instead of torch's
+    per-element exponential race."""
+    if _MODE == "reference" or k >= prob.numel() // 2:
+        return torch.multinomial(prob, k)
+    cdf = torch.cumsum(prob.double(), 0)
+    total = float(cdf[-1])
+    seen, out = set(), []
+    while len(out) < k:
+        u = torch.rand(2 * (k - len(out)) + 8, dtype=torch.float64) * total
+        for v in torch.searchsorted(cdf, u, right=True).clamp_(max=prob.numel() - 1).tolist():
+            if v not in seen:
+                seen.add(v)
+                out.append(v)
+                if len(out) == k:
+                    break
+    return torch.tensor(out, dtype=torch.int64)

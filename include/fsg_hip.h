@@ -68,7 +68,8 @@ const char* fsg_error_string(int code);
 /* Process-wide tuning switches (tests use them to cross-check the tuned kernels against the plain
  * ones); returns the previous flags.  Results are within the documented tolerances either way. */
 #define FSG_TUNE_GENERIC_WARP 1  /* per-voxel field evaluation instead of the row-wise LDS kernels */
-#define FSG_TUNE_PRECISE_MATH 2  /* OCML powf/expf in the gamma/bias epilogue instead of v_log/v_exp */
+#define FSG_TUNE_PRECISE_MATH 2  /* OCML powf/expf in the gamma/bias epilogue instead of v_log/v_exp; slice acquisition
+                                    forward in the CUDA source's operation order instead of pair loads + lerps */
 #define FSG_TUNE_GENERIC_ZOOM 4  /* per-voxel 8-tap zoom instead of the row-wise LDS kernels */
 #define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
 #define FSG_TUNE_NO_PATCH 32     /* row kernel (4 waves, own rows) instead of the 16-wave lockstep patch kernel */
