@@ -121,6 +121,77 @@ __global__ __launch_bounds__(256) void blur_contig_lds(const float* __restrict__
   }
 }
 
+
+// ---- long kernels (radius 9..64: BlurCortex draws sigma from a gamma distribution) -------------------------------
+// Same data movement as the two kernels above with the radius as a run-time value: the input loop is not unrolled,
+// every input row is offered to all TL outputs under a uniform predicate (useful work (2R+1)/(TL+2R)), taps are read
+// from the kernel arguments with a wave-uniform index (scalar loads).
+template <int TL>
+__global__ __launch_bounds__(256) void blur_strided_long(const float4* __restrict__ src, float4* __restrict__ dst, int len,
+                                                         int inner4, int R, Taps T) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int l0 = (blockIdx.y * 4 + threadIdx.y) * TL;
+  if (c >= inner4 || l0 >= len) return;
+  const size_t slab = (size_t)blockIdx.z * len * inner4;
+  const float4* s = src + slab + c;
+  float4 acc[TL];
+#pragma unroll
+  for (int o = 0; o < TL; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int t_lo = max(0, R - l0), t_hi = min(TL + 2 * R, len - l0 + R);  // rows inside the volume only
+  for (int t = t_lo; t < t_hi; ++t) {
+    const float4 v = s[(size_t)(l0 + t - R) * inner4];
+#pragma unroll
+    for (int o = 0; o < TL; ++o) {
+      const int tap = t - o;
+      if (tap >= 0 && tap <= 2 * R) {
+        const float w = T.w[tap];
+        acc[o].x = fmaf(w, v.x, acc[o].x);
+        acc[o].y = fmaf(w, v.y, acc[o].y);
+        acc[o].z = fmaf(w, v.z, acc[o].z);
+        acc[o].w = fmaf(w, v.w, acc[o].w);
+      }
+    }
+  }
+  float4* d = dst + slab + c;
+#pragma unroll
+  for (int o = 0; o < TL; ++o)
+    if (l0 + o < len) d[(size_t)(l0 + o) * inner4] = acc[o];
+}
+
+__global__ __launch_bounds__(256) void blur_contig_long(const float* __restrict__ src, float* __restrict__ dst, int rows, int nz,
+                                                        int R, Taps T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int RP = (R + 3) & ~3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pitch = nz + 2 * RP;
+  float* row = lds + (size_t)wave * pitch;
+  const int nz4 = nz >> 2;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * nz);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)r * nz);
+    for (int q = lane; q < RP / 4; q += 64) {
+      reinterpret_cast<float4*>(row)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(row + RP + nz)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int q = lane; q < nz4; q += 64) reinterpret_cast<float4*>(row + RP)[q] = s4[q];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int q = lane; q < nz4; q += 64) {
+      const float* wnd = row + 4 * q + (RP - R);  // input index (4q + e + t - R) lives at wnd[e + t]
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      float a = wnd[0], b = wnd[1], c = wnd[2];
+      for (int t = 0; t <= 2 * R; ++t) {
+        const float d = wnd[t + 3];
+        const float w = T.w[t];
+        o0 = fmaf(w, a, o0); o1 = fmaf(w, b, o1); o2 = fmaf(w, c, o2); o3 = fmaf(w, d, o3);
+        a = b; b = c; c = d;
+      }
+      d4[q] = make_float4(o0, o1, o2, o3);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int R>
 int launch_strided(const float* src, float* dst, int outer, int len, int inner, const Taps& T, hipStream_t st) {
 #ifndef FSG_BLUR_TL
@@ -191,6 +262,14 @@ extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx,
         case 8: return launch_contig<8>(src, dst, rows, nz, T, st);
       }
     }
+    if (aligned && (nz & 3) == 0 && R > 8 && nz <= 4096) {
+      const int RP = (R + 3) & ~3;
+      int grid = (rows + 3) / 4;
+      if (grid > 8192) grid = 8192;
+      hipLaunchKernelGGL(blur_contig_long, dim3(grid), dim3(256), (size_t)4 * (nz + 2 * RP + 4) * sizeof(float), st, src, dst,
+                         rows, nz, R, T);
+      FSG_RETURN_LAUNCH();
+    }
     return FSG_E_ALIGN;  // caller falls back to fsg_blur_axis_f32
   }
   int outer, len, inner;
@@ -207,6 +286,14 @@ extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx,
       case 7: return launch_strided<7>(src, dst, outer, len, inner, T, st);
       case 8: return launch_strided<8>(src, dst, outer, len, inner, T, st);
     }
+  }
+  if (aligned && (inner & 3) == 0 && R > 8) {
+    constexpr int TL = 16;
+    const int inner4 = inner / 4, chunks = (len + TL - 1) / TL;
+    dim3 block(64, 4), grid((unsigned)((inner4 + 63) / 64), (unsigned)((chunks + 3) / 4), (unsigned)outer);
+    hipLaunchKernelGGL(blur_strided_long<TL>, grid, block, 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), len, inner4, R, T);
+    FSG_RETURN_LAUNCH();
   }
   return FSG_E_ALIGN;
 }

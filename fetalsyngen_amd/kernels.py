@@ -693,7 +693,7 @@ def nonzero_ranks(vol, op=">", value=0.0):
 
 
 def box_sum3d(v, k: int) -> torch.Tensor:
-    """Zero-padded k x k x k box sum (conv3d with a ones kernel, padding k//2): three passes of the blur kernels
+    """Zero-padded k x k x k box sum (the reference convolves with a ones kernel, padding k//2): three passes of the blur kernels
     with unit taps (exact for the small integers of a binary mask)."""
     ones = np.ones(int(k), np.float32)
     for axis in range(3):

@@ -249,6 +249,28 @@ def test_blur_fast_paths_match_oracle_and_properties(K):
         assert (o[0] < 0.75).all() and (o[-1] < 0.75).all()
 
 
+def test_blur_long_kernels(K):
+    """Radius 9..64 (BlurCortex draws its sigmas from a gamma distribution, augmentation/artifacts.py:104): the run-time
+    radius kernels against the generic kernel and the oracle, including rows shorter than the kernel."""
+    from fetalsyngen_amd import tables as T
+
+    rs = np.random.RandomState(2)
+    for shape in [(64, 48, 64), (24, 40, 128)]:
+        x = (rs.rand(*shape) * 255).astype(np.float32)
+        for sigma in (3.0, 4.9, 7.3, 21.0):
+            taps = T.gaussian_taps(sigma)
+            assert len(taps) // 2 > 8
+            for axis in range(3):
+                a = K.blur_axis(dev(x), axis, taps)
+                b = K.blur_axis(dev(x), axis, taps, force_generic=True)
+                np.testing.assert_allclose(host(a), host(b), rtol=1e-6, atol=2e-4)
+        st = [4.9, 3.0, 7.3]
+        y = dev(x)
+        for axis in range(3):
+            y = K.blur_axis(y, axis, T.gaussian_taps(st[axis]))
+        np.testing.assert_allclose(host(y), O.blur3d(t(x), st).numpy(), rtol=RTOL, atol=ATOL)
+
+
 # ---- augmentation stages (un-fused API) -------------------------------------------------------------
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("gates", ["on", "off"])
