@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void mog_sum_kernel(const float* __restrict__ 
     const float* tx = tab + (size_t)(g * 3 + 0) * L;
     const float ty = tab[(size_t)(g * 3 + 1) * L + y];
     const float tz = tab[(size_t)(g * 3 + 2) * L + z];
+    // a blob whose (y,z) distance alone puts exp(-d/2) below the smallest normal fp32 (e^-88) adds nothing to this row:
+    // uniform skip (y, z are per-workgroup), which is what makes 200 narrow blobs cost as much as the few that reach a row
+    if (ty + tz > 176.f) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (x4 + q < W) {

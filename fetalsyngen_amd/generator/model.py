@@ -11,9 +11,9 @@ arrays in one copy, then runs the fused kernel sequence
         -> zoom min/max -> zoom+normalise
 
 `generate()` / `augment()` remain individually callable (stage by stage, un-fused).
-The optional SR-artifact stages (`blur_cortex`, `struct_noise`, `simulate_motion`, `boundaries`) are
-outside this package's scope; any callable with the reference's artifact signature is
-still applied in the reference's place.
+The optional SR-artifact stages (`blur_cortex`, `struct_noise`, `simulate_motion`, `boundaries`; mirrors in
+`fetalsyngen_amd.generator.augmentation.artifacts`) are applied after `resize_back` in the reference's order
+(model.py:207-219); any callable with the reference's artifact signature is accepted.
 """
 from __future__ import annotations
 
