@@ -788,7 +788,49 @@ def g_sr_boundaries(R):
     save("sr_boundaries", **out)
 
 
+def g_e2e_art(R):
+    """FetalSynthGen.sample with all four SR-artifact stages on (default YAML values, gates forced), 48^3, CPU."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    M = _ref_sr()
+    shape = (48, 48, 48)
+    seg, seeds = make_seed_volumes(shape, 0)
+    table, paths = {}, {}
+    for n_sub, d in seeds.items():
+        paths[n_sub] = {}
+        for m, vol in d.items():
+            table[f"seed_{n_sub}_{m}"] = torch.from_numpy(vol.copy())
+            paths[n_sub][m] = f"seed_{n_sub}_{m}"
+    out = {}
+    for case, seed in {"a": 3, "b": 10}.items():
+        sn_merge = M.AU.StructNoiseMergeParams(merge_type="perlin", gauss_nloc_min=5, gauss_nloc_max=15, gauss_sigma_mu=25,
+                                               gauss_sigma_std=5, perlin_res_list=[1, 2], perlin_octaves_list=[1, 2, 4],
+                                               perlin_persistence=0.5, perlin_lacunarity=2, perlin_increase_size=0.1)
+        arts = dict(
+            blur_cortex=M.ART.BlurCortex(prob=1.0, cortex_label=2, nblur_min=50, nblur_max=200),
+            struct_noise=M.ART.StructNoise(prob=1.0, wm_label=3, std_min=0.2, std_max=0.4, merge_params=sn_merge),
+            simulate_motion=M.ART.SimulateMotion(prob=1.0, scanner_params=M.AU.ScannerParams(**SCANNER_KW),
+                                                 recon_params=M.AU.ReconParams(**RECON_KW, merge_params=M.AU.ReconMergeParams(
+                                                     merge_type="perlin", **MERGE_KW))),
+            boundaries=M.ART.SimulatedBoundaries(prob_no_mask=0.0, prob_if_mask_halo=0.5, prob_if_mask_fuzzy=0.5),
+        )
+        gen = build_generator(R, shape, nonlin=(0.08, 0.2))
+        gen.artifacts = arts
+        gen.intensity_generator.loader = lambda p: table[p].clone()
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        y, seg_out, _img, params = gen.sample(image=None, segmentation=torch.from_numpy(seg), seeds=paths)
+        out[f"{case}_out"] = y.numpy()
+        out[f"{case}_seg"] = seg_out.numpy().astype(np.uint8)
+        out[f"{case}_next"] = _next_draws()
+        a = params["artifacts"]
+        out[f"{case}_meta"] = np.array([a["blur_cortex"]["nblur"], a["struct_noise"]["nstages"], a["simulate_motion"]["nstacks"],
+                                        int(bool(a["boundaries"]["halo_on"])), int(bool(a["boundaries"]["fuzzy_on"]))])
+    save("e2e_art_48", **out)
+
+
 ALL = {
+    "e2e_art": g_e2e_art,
     "sr_boundaries": g_sr_boundaries,
     "sr_units": g_sr_units, "sr_motion": g_sr_motion, "sr_volumetric": g_sr_volumetric,
     "slice_acq": g_slice_acq,

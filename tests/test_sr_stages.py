@@ -261,3 +261,31 @@ def test_config4_384_with_sr_artifacts(env):
     assert float((out[brain] > 0).float().mean()) > 0.97
     if art["boundaries"]["no_mask_on"] is False and not art["boundaries"]["halo_on"] and not art["boundaries"]["fuzzy_on"]:
         assert float(out[~brain].abs().max()) == 0.0
+
+
+# ---- the whole generator with every SR stage on, against a CPU run of the reference --------------------------------
+@pytest.mark.parametrize("case,seed", [("a", 3), ("b", 10)])
+def test_generator_with_all_sr_stages_vs_reference(env, golden, case, seed):
+    """FetalSynthGen.sample (GMM -> deform -> gamma -> bias -> resample -> noise -> zoom-back -> BlurCortex -> StructNoise ->
+    SimulateMotion -> SimulatedBoundaries) at 48^3, same numpy / torch seeds as the reference's CPU run: labels exact,
+    stage metadata and both RNG stream positions equal, image within tolerance except for isolated nearest-voxel flips."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+    from tests.util_cases import default_artifacts, make_generator
+
+    g = golden("e2e_art_48")
+    shape = (48, 48, 48)
+    seg, seeds = make_seed_volumes(shape, 0)
+    arts = default_artifacts(prob=1.0)
+    gen = make_generator(shape, DEV, nonlin_scale=(0.08, 0.2), rng="reference", artifacts=arts)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    y, seg_out, _img, params = gen.sample(image=None, segmentation=dev(seg.astype(np.float32)),
+                                          seeds={n: {m: torch.from_numpy(v) for m, v in d.items()} for n, d in seeds.items()})
+    a = params["artifacts"]
+    meta = np.array([a["blur_cortex"]["nblur"], a["struct_noise"]["nstages"], a["simulate_motion"]["nstacks"],
+                     int(bool(a["boundaries"]["halo_on"])), int(bool(a["boundaries"]["fuzzy_on"]))])
+    assert np.array_equal(meta, g[f"{case}_meta"])
+    assert np.array_equal(next_draws(), g[f"{case}_next"])
+    assert np.array_equal(host(seg_out).astype(np.uint8), g[f"{case}_seg"])
+    d = np.abs(host(y) - g[f"{case}_out"])
+    assert (d > 5e-4).mean() < 2e-3 and d.max() < 5e-2, (float((d > 5e-4).mean()), float(d.max()))
