@@ -122,6 +122,31 @@ def blur_microbench(shape, device, sigma=1.3, reps=20):
     return out
 
 
+def config4_sr(device, size=384, reps=3):
+    """BASELINE configs[3] side line (not the metric): the SR-artifact slice-stack simulation (SimulateMotion = Scanner.scan +
+    PSFReconstructor.recon_psf, default YAML ranges, device RNG) on one 384^3 / 0.5 mm volume, wall ms per volume."""
+    from fetalsyngen_amd.generator.defaults import default_artifacts
+    from fetalsyngen_amd.phantom import make_segmentation
+
+    shape = (size,) * 3
+    seg = torch.from_numpy(make_segmentation(shape)[0].astype(np.float32)).to(device)
+    img = (0.1 * seg + 0.05 * torch.rand(shape, device=device)) * (seg > 0)
+    img = img / img.max()
+    stage = default_artifacts(prob=1.0)["simulate_motion"]
+    ms, stacks = [], []
+    for rep in range(reps + 1):
+        np.random.seed(100 + rep)
+        torch.manual_seed(100 + rep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _y, meta = stage(img, seg, device, {}, resolution=[0.5, 0.5, 0.5])
+        torch.cuda.synchronize()
+        ms.append(round((time.perf_counter() - t0) * 1e3, 1))
+        stacks.append(int(meta["nstacks"]))
+    return {"workload": f"SimulateMotion on one {size}^3 volume (2-6 stacks of slices, PSF acquisition + reconstruction)",
+            "ms_per_volume": ms[1:], "nstacks": stacks[1:], "mean_ms": round(float(np.mean(ms[1:])), 1)}
+
+
 def cpu_baseline(shape, threads):
     """The CPU restatement of the reference path (oracle/, validated against the real reference by the
     golden vectors) timed on this host: one warm-up + one timed full-size sample."""
@@ -152,6 +177,7 @@ def main():
     ap.add_argument("--rng", default="device", choices=["device", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-sr", action="store_true", help="skip the 384^3 SimulateMotion side line")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the samples are spread over (round robin)")
     args = ap.parse_args()
 
@@ -267,6 +293,8 @@ def main():
     if rank == 0:
         if not args.no_microbench:
             result["blur_microbench"] = blur_microbench(shape, device)
+        if world == 1 and not args.no_sr:
+            result["config4_sr"] = config4_sr(device)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             result["cpu_baseline"] = cpu_baseline(shape, threads)

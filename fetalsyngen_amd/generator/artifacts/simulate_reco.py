@@ -217,17 +217,19 @@ class Scanner:
             transform_target = transform_motion.compose(transform_init)
 
             mat = K._upload(mat_update_resolution(transform_target.matrix(), res_r, res).contiguous(), device)
-            slices = slice_acquisition(mat, volume, None, None, psf_acq, (ss, ss), res_s / res, False, False)
+            # The reference acquires all ns slices through the PSF, then the 1-tap mask acquisition, and only then keeps
+            # the contiguous run of slices that see enough of the brain (ref :386-420).  The acquisitions draw nothing,
+            # so the cheap mask acquisition goes first here and the PSF acquisition is run for the kept run only.
             slices_no_psf = slice_acquisition(mat, data["mask"], None, None, psf_delta, (ss, ss), res_s / res, False, False)
-            # keep the contiguous run of slices that see enough of the brain (ref :408-420); one host sync
-            nnz = K.slice_sums(slices_no_psf.view(ns, ss, ss)).cpu()
+            nnz = K.slice_sums(slices_no_psf.view(ns, ss, ss)).cpu()  # one host sync per stack
             idx = nnz > (nnz.max() * np.random.uniform(0.1, 0.3))
             if idx.sum() == 0:
                 continue
             nz = torch.nonzero(idx)
             first, last = int(nz[0, 0]), int(nz[-1, 0])
             idx[first:last] = True
-            slices, slices_no_psf = slices[first : last + 1], slices_no_psf[first : last + 1]
+            slices = slice_acquisition(mat[first : last + 1], volume, None, None, psf_acq, (ss, ss), res_s / res, False, False)
+            slices_no_psf = slices_no_psf[first : last + 1]
             transform_init = reset_transform(transform_init[idx])
             transform_target = transform_target[idx]
             slices = self.random_gamma(slices)

@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from fetalsyngen_amd import rng  # noqa: E402
 from fetalsyngen_amd.phantom import make_segmentation  # noqa: E402
-from tests.util_cases import default_artifacts  # noqa: E402
+from fetalsyngen_amd.generator.defaults import default_artifacts  # noqa: E402
 
 
 def main():
