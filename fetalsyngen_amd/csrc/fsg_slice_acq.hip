@@ -210,7 +210,14 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
                                                                                   float* __restrict__ slices,
                                                                                   float* __restrict__ weights) {
   extern __shared__ float smem[];
-  const int in = blockIdx.z;
+  // XCD-aware work order: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so with the
+  // natural (tile, slice) order all eight L2s stream the same plate of the volume.  Linear id L -> XCD L % 8 owns the
+  // slices {x, x+8, ...}, walking each slice tile by tile: every plate is fetched into one L2 only.
+  const int tiles_x = (P.w + SA_TILE - 1) / SA_TILE, tiles = tiles_x * ((P.h + SA_TILE - 1) / SA_TILE);
+  const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+  const int in = (m / tiles) * 8 + xcd, tile = m % tiles;
+  if (in >= P.n) return;
+  const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);  // [<= np] (ox, oy, oz, psf)
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
   }
   __syncthreads();
   const int nt = ntaps_s;
-  const int ix = blockIdx.x * SA_TILE + threadIdx.x, iy = blockIdx.y * SA_TILE + threadIdx.y;
+  const int ix = bx * SA_TILE + threadIdx.x, iy = by * SA_TILE + threadIdx.y;
   const bool inside = ix < P.w && iy < P.h;
   const size_t idx = ((size_t)in * P.h + (inside ? iy : 0)) * P.w + (inside ? ix : 0);
   bool live = inside && !(P.smask && !P.smask[idx]);
@@ -749,8 +756,11 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<false, true>), grid, block, lds, st, P, vol, slices, slices_weight);
     else if ((g_tuning_flags & FSG_TUNE_PRECISE_MATH) || pd * ph * pw > 4000)  // (the fast kernel keeps 16 B per tap in LDS)
       hipLaunchKernelGGL((sa_forward_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight);
-    else hipLaunchKernelGGL(sa_forward_linear_fast_kernel, grid, block, (size_t)pd * ph * pw * 4 * sizeof(float), st, P, vol,
-                            slices, slices_weight);
+    else {
+      const unsigned tiles = grid.x * grid.y, groups = (unsigned)((n + 7) / 8);
+      hipLaunchKernelGGL(sa_forward_linear_fast_kernel, dim3(8u * tiles * groups), block,
+                         (size_t)pd * ph * pw * 4 * sizeof(float), st, P, vol, slices, slices_weight);
+    }
   } else {
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<true, true>), grid, block, lds, st, P, vol, slices, slices_weight);
     else hipLaunchKernelGGL((sa_forward_kernel<true, false>), grid, block, lds, st, P, vol, slices, slices_weight);
