@@ -730,6 +730,25 @@ def g_sr_motion(R):
     out["scan_psf_rec"] = ds["psf_rec"].numpy()
     out["scan_meta"] = np.array([ds["resolution_slice"], ds["slice_thickness"], ds["gap"]])
     out["scan_next"] = _next_draws()
+    # reconstruction grid coarser than the input grid (resolution_recon=None: drawn between the two resolutions), which
+    # resamples the ground truth with grid_sample (simulate_reco.py:319-328); then the reconstruction on that grid
+    np.random.seed(29)
+    torch.manual_seed(29)
+    d = {"resolution": np.float64(0.5), "volume": torch.from_numpy(img.copy())[None, None],
+         "mask": torch.from_numpy((seg > 0).astype(np.float32))[None, None], "seg": torch.from_numpy(seg.copy())[None, None],
+         "threshold": 0.1}
+    sc = M.SR.Scanner(**{**SCANNER_KW, "resolution_slice_fac_min": 1.6, "resolution_recon": None})
+    ds = sc.scan(d)
+    rp = M.AU.ReconParams(**{**RECON_KW, "prob_merge": 1.0}, merge_params=M.AU.ReconMergeParams(merge_type="perlin", **MERGE_KW))
+    rec = M.SR.PSFReconstructor(**{f: getattr(rp, f) for f in rp.__dataclass_fields__})
+    vol, w = rec.recon_psf(ds)
+    out["scanr_meta"] = np.array([ds["resolution_recon"], ds["resolution_slice"], ds["slice_thickness"], ds["gap"]])
+    out["scanr_volume_gt"] = ds["volume_gt"].numpy()[0, 0]
+    out["scanr_seg_gt"] = ds["seg_gt"].numpy()[0, 0].astype(np.uint8)
+    out["scanr_stacks"] = ds["stacks"].numpy()[:, 0]
+    out["scanr_recon"] = vol.numpy()[0, 0]
+    out["scanr_weight"] = w.numpy()
+    out["scanr_next"] = _next_draws()
     save("sr_motion", **out)
 
 

@@ -289,3 +289,30 @@ def test_generator_with_all_sr_stages_vs_reference(env, golden, case, seed):
     assert np.array_equal(host(seg_out).astype(np.uint8), g[f"{case}_seg"])
     d = np.abs(host(y) - g[f"{case}_out"])
     assert (d > 5e-4).mean() < 2e-3 and d.max() < 5e-2, (float((d > 5e-4).mean()), float(d.max()))
+
+
+def test_scan_and_recon_on_a_coarser_grid_vs_reference(env, golden):
+    """resolution_recon=None: the reconstruction resolution is drawn between the input and the slice resolution, the
+    ground truth is resampled onto that grid (grid_sample in the reference, simulate_reco.py:319-328; per-axis tables on
+    the zoom kernel here) and the reconstruction runs on the smaller grid (25^3 from 32^3)."""
+    g = golden("sr_motion")
+    np.random.seed(29)
+    torch.manual_seed(29)
+    img, seg = dev(g["img"]), dev(g["seg"])
+    d = {"resolution": np.float64(0.5), "volume": img[None, None], "mask": (seg > 0).float()[None, None],
+         "seg": seg[None, None], "threshold": 0.1}
+    sc = env.SR.Scanner(**{**SCANNER_KW, "resolution_slice_fac_min": 1.6, "resolution_recon": None})
+    ds = sc.scan(d)
+    assert np.array_equal(np.array([ds["resolution_recon"], ds["resolution_slice"], ds["slice_thickness"], ds["gap"]]),
+                          g["scanr_meta"])
+    np.testing.assert_allclose(host(ds["volume_gt"])[0, 0], g["scanr_volume_gt"], atol=2e-6)
+    assert np.array_equal(host(ds["seg_gt"])[0, 0].astype(np.uint8), g["scanr_seg_gt"])
+    dd = np.abs(host(ds["stacks"])[:, 0] - g["scanr_stacks"])
+    assert (dd > 2e-5).mean() < 1e-3 and dd.max() < 1e-2
+    rp = env.U.ReconParams(**{**RECON_KW, "prob_merge": 1.0}, merge_params=env.U.ReconMergeParams(merge_type="perlin", **MERGE_KW))
+    rec = env.SR.PSFReconstructor(**{f: getattr(rp, f) for f in rp.__dataclass_fields__})
+    vol, w = rec.recon_psf(ds)
+    assert np.array_equal(next_draws(), g["scanr_next"])
+    np.testing.assert_allclose(host(w).reshape(25, 25, 25), g["scanr_weight"], atol=1e-5)
+    dd = np.abs(host(vol)[0, 0] - g["scanr_recon"])
+    assert (dd > 2e-4).mean() < 1e-3 and dd.max() < 1e-2
