@@ -5,6 +5,8 @@ Drop-in surface (same names / signatures as the reference's `fetalsyngen` packag
     fetalsyngen_amd.generator.intensity.rand_gmm.ImageFromSeeds
     fetalsyngen_amd.generator.deformation.affine_nonrigid.SpatialDeformation
     fetalsyngen_amd.generator.augmentation.synthseg.{RandResample,RandBiasField,RandNoise,RandGamma}
+    fetalsyngen_amd.generator.augmentation.artifacts.{BlurCortex,StructNoise,SimulateMotion,SimulatedBoundaries}
+    fetalsyngen_amd.generator.artifacts.{utils,simulate_reco,svort}   (Scanner, PSFReconstructor, slice_acquisition, ...)
     fetalsyngen_amd.data.datasets.FetalSynthDataset
     fetalsyngen_amd.utils.generation.{make_affine_matrix,make_gaussian_kernel,gaussian_blur_3d,
                                       fast_3D_interp_torch,myzoom_torch}
