@@ -50,9 +50,25 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
   }
 }
 
+// byte copy by the compute queue: `src` may be pinned host memory (device-visible under unified addressing).  Used for
+// the per-sample parameter arena (<= 64 KB): a copy *kernel* in the launch stream instead of a memcpy command keeps the
+// whole sample in one queue.
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e];
+}
+
 }  // namespace
 
 extern "C" {
+
+int fsg_copy_bytes(void* dst, const void* src, size_t nbytes, void* stream) {
+  if (!dst || !src || nbytes == 0 || (nbytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return FSG_E_BADARG;
+  const size_t n16 = nbytes >> 4;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), (uint4*)dst, (const uint4*)src, n16);
+  FSG_RETURN_LAUNCH();
+}
 
 int fsg_reduce_minmax_f32(const float* x, size_t n, int32_t* mm, void* stream) {
   if (!x || !mm || n == 0) return FSG_E_BADARG;

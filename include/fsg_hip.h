@@ -212,6 +212,9 @@ int fsg_add_noise_f32(const float* x, size_t n, const float* noise, uint64_t see
 int fsg_reduce_minmax_f32(const float* x, size_t n, int32_t* mm, void* stream); /* mm[0]=min key, mm[1]=max key */
 /* mode 0: out = x / max;  mode 1: out = (x - min) / (max - min) (0*x if flat);  mode 2: (x-min)/(max-min)*255 */
 int fsg_scale_f32(const float* x, size_t n, const int32_t* mm, int mode, float* out, void* stream);
+/* dst[0..nbytes) = src[0..nbytes) by a kernel on `stream`; both 16-byte aligned, nbytes a multiple of 16.  `src` may be
+ * pinned host memory: the per-sample parameter arena is uploaded this way so that the sample stays in one hardware queue. */
+int fsg_copy_bytes(void* dst, const void* src, size_t nbytes, void* stream);
 /* Decode ordered keys on the host side helper (pure function, no GPU). */
 float fsg_key_to_float(int32_t key);
 
