@@ -146,6 +146,7 @@ SIGNATURES = {
     "fsg_bernoulli_keep_f32": [P, SZ, F, U64, U64, P, P],
     "fsg_scatter_const_f32": [P, P, I, F, P],
     "fsg_copy_bytes": [P, P, SZ, P],
+    "fsg_zoom_set_tuning": [I, I],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],

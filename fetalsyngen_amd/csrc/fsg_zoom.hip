@@ -326,6 +326,151 @@ __global__ __launch_bounds__(256, 8) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, 
   }
 }
 
+
+// ---- tile variant ---------------------------------------------------------------------------------------
+// SQ counters of the row kernels above at 256^3 (rocprofv3 --pmc, tools/kernel_bench.py --only zoom): ~92 VALU + ~108
+// SALU + 13 VMEM + 13 LDS wave-instructions per output row and a time that is linear in the number of rows and blind to
+// the number of cache lines fetched -- they are bound by instruction issue (one row per wave iteration: tap unpacking,
+// pointer arithmetic, LDS round trip and, with the Philox epilogue, one 10-round Philox block PER OUTPUT although a block
+// yields four normals).  This kernel spends its instructions on outputs instead:
+//   * workgroup = one x index and TY consecutive output y rows; the x-blended source rows those outputs can touch
+//     (a window of sy/dy * TY + 2 rows) are formed ONCE, coalesced, into LDS;
+//   * a thread then produces four consecutive outputs of the tile's contiguous output range: two y-blends of LDS
+//     values and one z-lerp per output (x -> y -> z, the operation order of fsg_tab_interp<1>: bit-identical), one
+//     Philox block per four outputs, one 16-byte store.
+// Falls back to the row kernels when the window does not fit the LDS budget.
+constexpr int ZT_MAX_TY = 32;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
+  extern __shared__ __attribute__((aligned(16))) float zt_smem[];
+  fsg_tap* tc = reinterpret_cast<fsg_tap*>(zt_smem);  // [dz] z taps
+  float* xs = zt_smem + 4 * Z.dz;                      // [window rows][sz] x-blended source rows
+  __shared__ fsg_tap tb[ZT_MAX_TY];
+  __shared__ int win[2];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_y = (Z.dy + TY - 1) / TY;
+  const int i = blockIdx.x / tiles_y, jt = blockIdx.x - i * tiles_y;
+  const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
+  float lo = INFINITY, hi = -INFINITY;
+  float mnq = 0.f, den = 1.f, mx = 1.f;
+  if (EPI == EPI_NORM) {
+    mx = fsg_key2f(E.mm_in[1]);
+    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    den = 1.0f - mnq;
+  }
+  // y taps of the tile and the window of source rows they reference
+  if (tid < 64) {
+    fsg_tap t = fsg_tap{-1, 0, 0.f, 0.f};
+    if (tid < nj) {
+      t = Z.ty[j0 + tid];
+      tb[tid] = t;
+    }
+    int smin = t.lo >= 0 ? t.lo : 0x7FFFFFFF, smax = t.lo >= 0 ? t.hi : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      smin = min(smin, __shfl_xor(smin, o, FSG_WAVE));
+      smax = max(smax, __shfl_xor(smax, o, FSG_WAVE));
+    }
+    if (tid == 0) { win[0] = smin; win[1] = smax; }
+  }
+  __syncthreads();
+  const fsg_tap a = zuniform_tap(Z.tx, i);
+  const int smin = win[0], nrows = win[1] - win[0] + 1;
+  const bool okx = a.lo >= 0 && nrows > 0;
+  const bool fits = nrows * Z.sz <= cap_floats;  // uniform
+  for (int k = tid; k < Z.dz; k += 256) tc[k] = Z.tz[k];
+  if (okx && fits) {
+    const float* pa = Z.src + ((size_t)a.lo * Z.sy + smin) * Z.sz;
+    const float* pb = Z.src + ((size_t)a.hi * Z.sy + smin) * Z.sz;
+    const int tot = nrows * Z.sz;  // the window rows are contiguous in the source: one linear, coalesced sweep
+    for (int e = tid; e < tot; e += 256) xs[e] = fsg_mix(a.w_lo, pa[e], a.w_hi, pb[e]);
+  }
+  __syncthreads();
+  const size_t base = ((size_t)i * Z.dy + j0) * Z.dz;  // first output of the tile
+  const size_t end = base + (size_t)nj * Z.dz;
+  const float inv_dz = 1.0f / (float)Z.dz;
+  for (size_t q = (base >> 2) + tid; (q << 2) < end; q += 256) {
+    const size_t o0 = q << 2;
+    float v[4];
+    bool live[4];
+    // (row, k) of the first live element of the quad
+    const size_t first = o0 < base ? base : o0;
+    int rel = (int)(first - base);
+    int jj = (int)((float)rel * inv_dz);
+    int k = rel - jj * Z.dz;
+    if (k < 0) { --jj; k += Z.dz; }
+    if (k >= Z.dz) { ++jj; k -= Z.dz; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t o = o0 + u;
+      live[u] = o >= base && o < end;
+      v[u] = 0.f;
+      if (live[u]) {
+        const fsg_tap b = tb[jj];
+        const fsg_tap c = tc[k];
+        if (okx && b.lo >= 0 && c.lo >= 0) {
+          if (fits) {
+            const float* xl = xs + (b.lo - smin) * Z.sz;
+            const float* xh = xs + (b.hi - smin) * Z.sz;
+            const float ylo = fsg_mix(b.w_lo, xl[c.lo], b.w_hi, xh[c.lo]);
+            const float yhi = fsg_mix(b.w_lo, xl[c.hi], b.w_hi, xh[c.hi]);
+            v[u] = fsg_mix(c.w_lo, ylo, c.w_hi, yhi);
+          } else {  // window larger than the launch reserved (tables that are not a plain zoom)
+            v[u] = fsg_tab_interp<1>(Z.src, Z.sy, Z.sz, 0, a, b, c);
+          }
+        }
+        if (++k == Z.dz) { k = 0; ++jj; }
+      }
+    }
+    if (EPI == EPI_NOISE_PHILOX) {
+      const float4 z = fsg_randn4(E.seed, E.stream_id, (uint64_t)q);
+      v[0] += E.noise_std * z.x; v[1] += E.noise_std * z.y; v[2] += E.noise_std * z.z; v[3] += E.noise_std * z.w;
+    } else if (EPI == EPI_NOISE_PTR) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) v[u] += E.noise_std * E.noise[o0 + u];
+    }
+    if (EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = v[u] < 0.f ? 0.f : v[u];
+    } else if (EPI == EPI_NORM) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t = v[u] / mx;
+        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (t - mnq) / den;
+        v[u] = t;
+      }
+    }
+    if (EPI == EPI_MINMAX) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+    } else if (live[0] && live[3] && ((((uintptr_t)Z.dst) & 15) == 0)) {
+      *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live[u]) Z.dst[o0 + u] = v[u];
+    }
+  }
+  if (EPI == EPI_MINMAX) {
+    lo = fsg_wave_min(lo);
+    hi = fsg_wave_max(hi);
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+      fsg_atomic_min_key(&E.mm_out[0], lo);
+      fsg_atomic_max_key(&E.mm_out[1], hi);
+    }
+  }
+}
+
+int g_zoom_ty = 16;            // output y rows per workgroup of zoom_tile_kernel
+int g_zoom_cap = 12288;        // LDS floats for the x-blended source window (48 KB)
+
 int check(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty, const fsg_tap* tz, int dx,
           int dy, int dz) {
   if (!src || !tx || !ty || !tz) return FSG_E_BADARG;
@@ -337,6 +482,22 @@ int check(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg
 template <int EPI>
 int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   const int rows = Z.dx * Z.dy;
+  // measured at 256^3: the tile kernel wins where the Philox epilogue dominates (down-sampling + noise, K7: 27 vs 33 us
+  // at m = 171, 42 vs 68 us at m = 256); the row kernels stay ahead for the up-sampling passes of K9 (30 vs 35-38 us)
+  if ((EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR || (g_tuning_flags & FSG_TUNE_TILE_ZOOM)) &&
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM))) {
+    // window estimate for the tile kernel: TY rows advance sy/dy source rows each (+2 for the pair and rounding)
+    int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
+    if (TY > Z.dy) TY = Z.dy;
+    const long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
+    if (TY >= 1 && est <= g_zoom_cap && Z.dz <= 2048) {
+      const int tiles_y = (Z.dy + TY - 1) / TY;
+      const size_t lds = ((size_t)est + 4 * (size_t)Z.dz) * sizeof(float);  // window + z taps: as many workgroups per CU as fit
+      hipLaunchKernelGGL(zoom_tile_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), lds, fsg_stream(stream), Z, E, TY,
+                         (int)est);
+      FSG_RETURN_LAUNCH();
+    }
+  }
   if (Z.sz <= ZROWCAP && !(g_tuning_flags & FSG_TUNE_GENERIC_ZOOM)) {
     // 2048 blocks when there is enough work: >= 8 rows per block keeps neighbouring rows (shared source
     // rows) on one CU, and the MINMAX variant issues only 2 atomics per block
@@ -390,6 +551,13 @@ int fsg_resample_noise_f32(const float* src, int sx, int sy, int sz, const fsg_t
     case 2: return launch1<EPI_NOISE_PHILOX>(Z, E, stream);
     default: return FSG_E_BADARG;
   }
+}
+
+int fsg_zoom_set_tuning(int y_rows, int cap_floats) {
+  if (y_rows < 1 || y_rows > ZT_MAX_TY || cap_floats < 256 || cap_floats > 16000) return FSG_E_BADARG;
+  g_zoom_ty = y_rows;
+  g_zoom_cap = cap_floats;
+  return 0;
 }
 
 int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,

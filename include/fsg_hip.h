@@ -74,6 +74,8 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
 #define FSG_TUNE_NO_PATCH 32     /* row kernel (4 waves, own rows) instead of the 16-wave lockstep patch kernel */
 #define FSG_TUNE_BUFFER_LOADS 64 /* opt in: patch kernel body on raw buffer loads (fewer instructions, slower in r01) */
+#define FSG_TUNE_ROW_ZOOM 256    /* resample + noise (K7): the row-per-wave kernels instead of the tile kernel */
+#define FSG_TUNE_TILE_ZOOM 512   /* every zoom through the tile kernel (default: only the noise epilogues) */
 #define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
@@ -122,6 +124,9 @@ int fsg_resample_noise_f32(const float* src, int sx, int sy, int sz, const fsg_t
                            const float* noise, uint64_t seed, uint64_t stream_id, float noise_std,
                            void* stream);
 
+/* Tile shape of the zoom kernels: output y rows per workgroup (1..32, default 16) and the LDS floats reserved for the
+ * x-blended source-row window (default 12288); a tile whose window does not fit is evaluated without staging. */
+int fsg_zoom_set_tuning(int y_rows, int cap_floats);
 /* K9 pass A (synthseg.py:111-112): min and max of zoom(src) without storing it; mm[0]=min, mm[1]=max as
  * order-preserving int32 keys (see fsg_minmax_init). */
 int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,

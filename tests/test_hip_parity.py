@@ -249,6 +249,44 @@ def test_blur_fast_paths_match_oracle_and_properties(K):
         assert (o[0] < 0.75).all() and (o[-1] < 0.75).all()
 
 
+def test_zoom_tile_kernel_equals_row_kernels(K):
+    """The tile kernel (x-blended source rows staged once per workgroup, four outputs and one Philox block per thread) against
+    the row-per-wave kernels, for every epilogue, up- and down-sampling, ragged sizes: bit-identical (same x -> y -> z
+    operation order, same Philox counter -> element mapping)."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import tables as T
+
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    for shape, m in (((64, 64, 64), 43), ((48, 40, 36), 29), ((40, 72, 128), 97), ((64, 64, 64), 64)):
+        x = dev((rs.rand(*shape) * 255).astype(np.float32))
+        spacing = [0.5 * n / max(int(n * m / shape[0]), 1) for n in shape]
+        stds, new, fac, rtabs = T.resample_plan(shape, [0.5] * 3, spacing, 0.5)
+        rt = K.DeviceTables(rtabs, DEV)
+        bt, _ = T.zoom_tables(new, 1 / np.asarray(fac))
+        zt = K.DeviceTables(bt, DEV)
+        res = {}
+        for flag in (256, 512):  # FSG_TUNE_ROW_ZOOM, FSG_TUNE_TILE_ZOOM
+            prev = lib.fsg_set_tuning(flag)
+            try:
+                for ty in ((16,) if flag == 256 else (1, 5, 16, 32)):
+                    lib.fsg_zoom_set_tuning(ty, 12288)
+                    low = K.resample_noise(x, rt, noise_std=9.0, seed=11, stream_id=2)
+                    z = K.randn(tuple(new), 5, 6, DEV)
+                    low2 = K.resample_noise(x, rt, noise_std=3.0, noise=z)
+                    plain = K.zoom3d(x, rt)
+                    mm = K.zoom_minmax(low, zt)
+                    up = [K.zoom_normalise(low, zt, mm, mode) for mode in (0, 1)]
+                    res[(flag, ty)] = [low, low2, plain, mm] + up
+            finally:
+                lib.fsg_set_tuning(prev)
+                lib.fsg_zoom_set_tuning(16, 12288)
+        ref = res[(256, 16)]
+        for key, val in res.items():
+            for a, b in zip(ref, val):
+                assert torch.equal(a, b), (shape, m, key)
+
+
 def test_blur_long_kernels(K):
     """Radius 9..64 (BlurCortex draws its sigmas from a gamma distribution, augmentation/artifacts.py:104): the run-time
     radius kernels against the generic kernel and the oracle, including rows shorter than the kernel."""
