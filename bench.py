@@ -191,6 +191,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        # one process per GPU: keep each rank's host-side plans (small numpy / torch CPU ops) on its share of the cores
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
 
     from fetalsyngen_amd import _lib
     from fetalsyngen_amd import sharding
