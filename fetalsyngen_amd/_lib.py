@@ -144,7 +144,7 @@ SIGNATURES = {
     "fsg_dist_pass_f32": [P, P, I, I, I, I, I, I, I, P],
     "fsg_boundary_mask_f32": [P, P, P, P, P, I, SZ, P, P, P],
     "fsg_bernoulli_keep_f32": [P, SZ, F, U64, U64, P, P],
-    "fsg_scatter_const_f32": [P, P, I, F, P],
+    "fsg_scatter_const_f32": [P, SZ, P, I, F, P],
     "fsg_copy_bytes": [P, P, SZ, P],
     "fsg_zoom_set_tuning": [I, I],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],

@@ -372,10 +372,10 @@ __global__ __launch_bounds__(256) void bernoulli_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void scatter_const_kernel(float* __restrict__ out, const long long* __restrict__ idx, int k,
-                                                            float value) {
+__global__ __launch_bounds__(256) void scatter_const_kernel(float* __restrict__ out, size_t n, const long long* __restrict__ idx,
+                                                            int k, float value) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < k && idx[q] >= 0) out[idx[q]] = value;
+  if (q < k && idx[q] >= 0 && (size_t)idx[q] < n) out[idx[q]] = value;
 }
 
 }  // namespace
@@ -534,9 +534,9 @@ int fsg_bernoulli_keep_f32(const float* a, size_t n, float p, uint64_t seed, uin
   FSG_RETURN_LAUNCH();
 }
 
-int fsg_scatter_const_f32(float* out, const long long* idx, int k, float value, void* stream) {
-  if (!out || !idx || k <= 0) return FSG_E_BADARG;
-  hipLaunchKernelGGL(scatter_const_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, fsg_stream(stream), out, idx, k,
+int fsg_scatter_const_f32(float* out, size_t n, const long long* idx, int k, float value, void* stream) {
+  if (!out || !idx || k <= 0 || n == 0) return FSG_E_BADARG;
+  hipLaunchKernelGGL(scatter_const_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, fsg_stream(stream), out, n, idx, k,
                      value);
   FSG_RETURN_LAUNCH();
 }

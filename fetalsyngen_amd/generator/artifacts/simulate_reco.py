@@ -429,8 +429,7 @@ class PSFReconstructor:
         trf = self.misregistration_trf(data.get("positions_host", data["positions"]), trf)
         kept_idx = self.kept_slices_idx(data["stacks"].shape[0])
         mats = K._upload(trf.matrix()[kept_idx].contiguous(), self.device)
-        ids = K._upload(kept_idx.to(torch.int32), self.device)
-        volume = rec(mats, data["stacks"], slice_ids=ids)  # the kept slices are addressed in place, not gathered
+        volume = rec(mats, data["stacks"], slice_ids=kept_idx)  # the kept slices are addressed in place, not gathered
         volume = self.smooth_volume(volume)
         # the reference forms `mask = seg_gt > 0` here (:772); only the Gaussian merge reads it, and the
         # voxel-selection kernels apply the `> 0` test to the label map directly

@@ -498,16 +498,21 @@ def slice_acq_forward(transforms, vol, vol_mask, slices_mask, psf, slice_shape, 
 def slice_acq_adjoint(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf=False,
                       equalize=False, semantics="cuda", return_weight=False, slice_ids=None):
     """(n,h,w) slices -> (D,H,W) volume  (fsg_slice_acq_adjoint_f32 + fsg_equalize_f32).
-    slice_ids (int32, device, len(transforms)): use slices[slice_ids[z]] for transform z (subset without a copy)."""
+    slice_ids (host integer tensor, len(transforms)): use slices[slice_ids[z]] for transform z (subset without a copy)."""
     n, (pd, ph, pw) = _sa_common(transforms, psf)
-    _need_gpu(slices, slice_ids)
+    _need_gpu(slices)
     _f32(slices, "slices")
     ns = int(slices.shape[0])
     if slices.dim() != 3 or (slice_ids is None and ns != n):
         raise ValueError(f"slices must be (n,h,w) with n={n}, got {tuple(slices.shape)}")
     if slice_ids is not None:
-        if slice_ids.dtype != torch.int32 or slice_ids.numel() != n:
-            raise ValueError("slice_ids must be int32 with one entry per transform")
+        # host tensor on purpose: the ids index device memory, so they are range-checked here before a kernel sees them
+        if slice_ids.is_cuda or slice_ids.numel() != n:
+            raise ValueError("slice_ids must be a host integer tensor with one entry per transform")
+        ids = slice_ids.to(torch.int64)
+        if n and (int(ids.min()) < 0 or int(ids.max()) >= ns):
+            raise IndexError(f"slice_ids out of range for {ns} slices")
+        slice_ids = _upload(ids.to(torch.int32).contiguous(), slices.device)
     h, w = int(slices.shape[1]), int(slices.shape[2])
     D, H, W = (int(v) for v in vol_shape)
     vm, sm = _sa_mask(vol_mask, (D, H, W), "vol_mask"), _sa_mask(slices_mask, (ns, h, w), "slices_mask")
@@ -815,6 +820,6 @@ def scatter_ones(shape, flat_idx, device):
     _need_gpu(flat_idx)
     out = torch.zeros(tuple(shape), dtype=F32, device=device)
     if flat_idx.numel():
-        _lib.check(_lib.load().fsg_scatter_const_f32(_p(out), _p(flat_idx.contiguous()), int(flat_idx.numel()), 1.0,
-                                                     _stream(out)), "fsg_scatter_const_f32")
+        _lib.check(_lib.load().fsg_scatter_const_f32(_p(out), out.numel(), _p(flat_idx.contiguous()), int(flat_idx.numel()),
+                                                     1.0, _stream(out)), "fsg_scatter_const_f32")
     return out

@@ -339,8 +339,8 @@ int fsg_boundary_mask_f32(const float* image, const float* mask, const float* ma
                           int n_dilate, size_t n, float* out, float* mask_out, void* stream);
 /* out = a * (u < p), u ~ U[0,1) from Philox(seed, stream_id) per element: device-RNG thinning of a voxel set. */
 int fsg_bernoulli_keep_f32(const float* a, size_t n, float p, uint64_t seed, uint64_t stream_id, float* out, void* stream);
-/* out[idx[q]] = value for q < k (idx DEVICE int64, negative entries skipped). */
-int fsg_scatter_const_f32(float* out, const long long* idx, int k, float value, void* stream);
+/* out[idx[q]] = value for q < k (idx DEVICE int64; entries outside [0, n) are skipped). */
+int fsg_scatter_const_f32(float* out, size_t n, const long long* idx, int k, float value, void* stream);
 
 /* ---- whole-sample launch sequence -------------------------------------------------------------------------- */
 /* One call = the fused kernel sequence of FetalSynthGen.sample (generator/model.py:231-276) for the

@@ -150,8 +150,10 @@ def test_adjoint_slice_subset_without_copy(K, golden):
     a = K.slice_acq_adjoint(tr[keep.to(DEV)].contiguous(), psf, s[keep.to(DEV)].contiguous(), None, None, VS, RES,
                             interp_psf=True, equalize=True)
     b = K.slice_acq_adjoint(tr[keep.to(DEV)].contiguous(), psf, s, None, None, VS, RES, interp_psf=True, equalize=True,
-                            slice_ids=keep.to(torch.int32).to(DEV))
+                            slice_ids=keep)
     np.testing.assert_allclose(host(a), host(b), rtol=0, atol=1e-4)
+    with pytest.raises(IndexError):
+        K.slice_acq_adjoint(tr[:3].contiguous(), psf, s, None, None, VS, RES, slice_ids=torch.tensor([0, 5, 1]))
 
 
 @pytest.mark.parametrize("tuning", [(4096, 0, 20), (4096, 3, 20), (8192, 6, 20), (512, 1, 0), (2048, 2, 0), (16384, 64, 1000)])
