@@ -14,6 +14,7 @@ from __future__ import annotations
 from functools import lru_cache
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -124,14 +125,16 @@ class _StagingRing:
         self.buf = torch.empty((self.SLOTS, self.SLOT), dtype=torch.uint8, pin_memory=True)
         self.events = [None] * self.SLOTS
         self.next = 0
+        self.lock = threading.Lock()
 
     def raw_stream(self):
         idx = self.device.index
         return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
     def acquire(self):
-        slot = self.next
-        self.next = (slot + 1) % self.SLOTS
+        with self.lock:
+            slot = self.next
+            self.next = (slot + 1) % self.SLOTS
         ev = self.events[slot]
         if ev is not None:
             ev.synchronize()
