@@ -8,8 +8,6 @@ seed-matched comparison with a CPU run of the reference).  There is no CPU path 
 """
 from __future__ import annotations
 
-import torch
-
 from .... import kernels as K
 
 _SEMANTICS = "cuda"

@@ -11,7 +11,6 @@ draw after the first Perlin field of a sample is not seed-reproducible in the re
 """
 from __future__ import annotations
 
-import copy  # noqa: F401  (kept: reference module namespace)
 from dataclasses import asdict, fields
 
 import numpy as np
