@@ -490,7 +490,7 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;
     const long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-    if (TY >= 1 && est <= g_zoom_cap && Z.dz <= 2048) {
+    if (TY >= 1 && est <= g_zoom_cap && est + 4LL * Z.dz <= 16000) {  // window + z taps within the 64 KB dynamic-LDS limit
       const int tiles_y = (Z.dy + TY - 1) / TY;
       const size_t lds = ((size_t)est + 4 * (size_t)Z.dz) * sizeof(float);  // window + z taps: as many workgroups per CU as fit
       hipLaunchKernelGGL(zoom_tile_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), lds, fsg_stream(stream), Z, E, TY,
