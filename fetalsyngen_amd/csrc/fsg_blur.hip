@@ -262,7 +262,7 @@ extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx,
         case 8: return launch_contig<8>(src, dst, rows, nz, T, st);
       }
     }
-    if (aligned && (nz & 3) == 0 && R > 8 && nz <= 4096) {
+    if (aligned && (nz & 3) == 0 && R > 8 && nz + 2 * ((R + 3) & ~3) + 4 <= 4096) {  // 4 staged rows within 64 KB of LDS
       const int RP = (R + 3) & ~3;
       int grid = (rows + 3) / 4;
       if (grid > 8192) grid = 8192;
