@@ -250,7 +250,7 @@ extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx,
   const bool aligned = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
   if (axis == 2) {
     const int rows = nx * ny;
-    if (aligned && (nz & 3) == 0 && R >= 1 && R <= 8 && nz <= 4096) {
+    if (aligned && (nz & 3) == 0 && R >= 1 && R <= 8 && nz <= 4064) {  // 4 rows + halos within 64 KB of LDS
       switch (R) {
         case 1: return launch_contig<1>(src, dst, rows, nz, T, st);
         case 2: return launch_contig<2>(src, dst, rows, nz, T, st);
