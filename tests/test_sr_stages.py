@@ -352,3 +352,33 @@ def test_dataset_with_default_sr_stages(env, tmp_path):
     finally:
         sa.set_semantics(prev_sem)
         rng.set_mode(prev_rng)
+
+
+def test_cuda_and_fallback_semantics_agree_statistically(env, golden):
+    """The reference's two slice-acquisition arithmetics (CUDA kernels: trilinear sampling / re-interpolated PSF; torch fallback:
+    nearest voxel / raw taps) are different discretisations of the same operator.  Same scene, same seeds: the two
+    reconstructions must be close (a third anchor for the otherwise unpinned CUDA arithmetic)."""
+    from fetalsyngen_amd.generator.artifacts.svort import slice_acq as sa
+
+    g = golden("sr_motion")
+    img, seg = dev(g["img"]), dev(g["seg"])
+    outs = {}
+    for sem in ("torch", "cuda"):
+        prev = sa.set_semantics(sem)
+        try:
+            np.random.seed(6)
+            torch.manual_seed(6)
+            sp = env.U.ScannerParams(**{**SCANNER_KW, "prob_gamma": 0.0, "prob_void": 0.0, "noise_sigma_max": 0.0})
+            rp = env.U.ReconParams(**{**RECON_KW, "prob_merge": 0.0, "prob_misreg_stack": 0.0, "prob_misreg_slice": 0.0,
+                                      "prob_rm_slices": 0.0, "prob_smooth": 0.0},
+                                   merge_params=env.U.ReconMergeParams(merge_type="perlin", **MERGE_KW))
+            y, meta = env.ART.SimulateMotion(prob=1.0, scanner_params=sp, recon_params=rp)(img, seg, DEV, {}, resolution=[0.5] * 3)
+            outs[sem] = host(y)
+        finally:
+            sa.set_semantics(prev)
+    a, b = outs["torch"], outs["cuda"]
+    brain = g["seg"] > 0
+    both = brain & (a > 0) & (b > 0)
+    assert both.mean() > 0.5 * brain.mean()
+    assert np.corrcoef(a[both], b[both])[0, 1] > 0.97
+    assert np.abs(a[both] - b[both]).mean() < 0.03 * a[both].mean() + 0.01
