@@ -118,6 +118,17 @@ def blur_microbench(shape, device, sigma=1.3, reps=20):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             res[f"axis{axis}"] = {"us": round(us, 2), "GBps": round(8.0 * nvox / us / 1e3, 1)}
+        # the y and z passes as one launch: two passes' algorithmic bytes (16 B/voxel)
+        if K.blur_yz(pool[0], taps, taps) is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for r in range(reps):
+                K.blur_yz(pool[r % len(pool)], taps, taps)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            res["fused_yz"] = {"us": round(us, 2), "GBps": round(16.0 * nvox / us / 1e3, 1)}
         out[label] = res
     return out
 

@@ -122,6 +122,7 @@ SIGNATURES = {
     "fsg_bias_mul_f32": [P, I, I, I, P, I, I, I, P, P, P, P, P],
     "fsg_blur_axis_f32": [P, P, I, I, I, I, P, I, P],
     "fsg_blur_axis_taps_host_f32": [P, P, I, I, I, I, C.POINTER(C.c_float), I, P],
+    "fsg_blur_yz_taps_host_f32": [P, P, I, I, I, C.POINTER(C.c_float), I, C.POINTER(C.c_float), I, P],
     "fsg_add_noise_f32": [P, SZ, P, U64, U64, F, P, P],
     "fsg_reduce_minmax_f32": [P, SZ, P, P],
     "fsg_scale_f32": [P, SZ, P, I, P, P],

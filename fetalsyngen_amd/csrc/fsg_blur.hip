@@ -192,6 +192,100 @@ __global__ __launch_bounds__(256) void blur_contig_long(const float* __restrict_
   }
 }
 
+
+// ---- fused y + z pass ----------------------------------------------------------------------------------------
+// The y and z passes of the separable blur as ONE kernel: a workgroup owns a TY x TZ tile of one x-plane, stages the
+// tile with its (Ry, Rz) halos in LDS (zeros outside the volume = the reference's zero padding), runs the y pass for
+// the tile's rows over the z-halo'd width into a second LDS buffer, then the z pass from there to global memory.  The
+// intermediate volume of the two-launch form (4 B/voxel written + 4 B/voxel read, and a launch) never exists.  Each pass
+// accumulates its taps in ascending order with fmaf exactly as the single-axis kernels do, on the same values, so the
+// result is bit-identical to running them one after the other.
+constexpr int YZ_MAXR = 8;
+constexpr int YZ_TL = 8;               // y outputs per thread (register sliding window)
+constexpr int YZ_ROWS = 4 * YZ_TL;     // y rows per workgroup
+
+// Workgroup = YZ_ROWS consecutive y rows of one x-plane over the FULL z extent (nz <= 512), thread = (float4 z-column,
+// y chunk), i.e. the body of blur_strided_v4 with TL = 8 whose results go to LDS rows (zero halo of RP floats either
+// side) instead of HBM; after a barrier every wave runs the body of blur_contig_lds over its rows of that LDS tile.
+template <int R>
+__global__ __launch_bounds__(256) void blur_yz_fused_kernel(const float4* __restrict__ src, float* __restrict__ dst, int ny,
+                                                            int nz, Taps T) {
+  constexpr int RP = (R + 3) & ~3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [YZ_ROWS][nz + 2 RP]
+  const int inner4 = nz >> 2, pitch = nz + 2 * RP;
+  const int tx = threadIdx.x, tyc = threadIdx.y;  // 64 x 4
+  const int y0 = blockIdx.x * YZ_ROWS;
+  const size_t plane4 = (size_t)blockIdx.y * ny * inner4;
+  // zero halos of every row
+  for (int e = tyc * 64 + tx; e < YZ_ROWS * (2 * RP / 4); e += 256) {
+    const int r = e / (2 * RP / 4), h = e - r * (2 * RP / 4);
+    float* row = lds + (size_t)r * pitch;
+    reinterpret_cast<float4*>(h < RP / 4 ? row : row + RP + nz)[h < RP / 4 ? h : h - RP / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ---- y pass (axis 1) into LDS ----
+  for (int c = tx; c < inner4; c += 64) {
+    const int l0 = y0 + tyc * YZ_TL;
+    const float4* s = src + plane4 + c;
+    float4 acc[YZ_TL];
+#pragma unroll
+    for (int o = 0; o < YZ_TL; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < YZ_TL + 2 * R; ++t) {
+      const int l = l0 + t - R;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l >= 0 && l < ny) v = s[(size_t)l * inner4];
+#pragma unroll
+      for (int o = 0; o < YZ_TL; ++o) {
+        const int tap = t - o;
+        if (tap >= 0 && tap <= 2 * R) {
+          const float w = T.w[tap];
+          acc[o].x = fmaf(w, v.x, acc[o].x);
+          acc[o].y = fmaf(w, v.y, acc[o].y);
+          acc[o].z = fmaf(w, v.z, acc[o].z);
+          acc[o].w = fmaf(w, v.w, acc[o].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < YZ_TL; ++o)
+      reinterpret_cast<float4*>(lds + (size_t)(tyc * YZ_TL + o) * pitch + RP)[c] = acc[o];
+  }
+  __syncthreads();
+  // ---- z pass (axis 2) from LDS to HBM: wave w takes rows w, w+4, ... ----
+  const int wave = tyc, lane = tx;
+  for (int r = wave; r < YZ_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ny) break;
+    const float* row = lds + (size_t)r * pitch;
+    float4* d4 = reinterpret_cast<float4*>(dst + ((size_t)blockIdx.y * ny + y) * nz);
+    for (int q = lane; q < inner4; q += 64) {
+      float win[4 + 2 * RP];
+#pragma unroll
+      for (int u = 0; u < (4 + 2 * RP) / 4; ++u) {
+        const float4 t = reinterpret_cast<const float4*>(row)[q + u];
+        win[4 * u] = t.x; win[4 * u + 1] = t.y; win[4 * u + 2] = t.z; win[4 * u + 3] = t.w;
+      }
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t <= 2 * R; ++t) {
+        const float w = T.w[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(w, win[RP - R + e + t], o[e]);
+      }
+      d4[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <int R>
+int launch_yz(const float* src, float* dst, int nx, int ny, int nz, const Taps& T, hipStream_t st) {
+  constexpr int RP = (R + 3) & ~3;
+  const size_t lds = (size_t)YZ_ROWS * (nz + 2 * RP) * sizeof(float);
+  dim3 grid((unsigned)((ny + YZ_ROWS - 1) / YZ_ROWS), (unsigned)nx), block(64, 4);
+  hipLaunchKernelGGL(blur_yz_fused_kernel<R>, grid, block, lds, st, reinterpret_cast<const float4*>(src), dst, ny, nz, T);
+  FSG_RETURN_LAUNCH();
+}
+
 template <int R>
 int launch_strided(const float* src, float* dst, int outer, int len, int inner, const Taps& T, hipStream_t st) {
 #ifndef FSG_BLUR_TL
@@ -296,4 +390,35 @@ extern "C" int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx,
     FSG_RETURN_LAUNCH();
   }
   return FSG_E_ALIGN;
+}
+
+// y pass followed by z pass in one launch (see blur_yz_fused_kernel); same result contract as two
+// fsg_blur_axis_taps_host_f32 calls (axis 1 then axis 2).  Serves the isotropic case the generator produces (the same
+// taps on both axes, radius 1..8), 16-byte aligned volumes, nz % 4 == 0; returns FSG_E_ALIGN otherwise (the caller then
+// issues the two single-axis passes).
+extern "C" int fsg_blur_yz_taps_host_f32(const float* src, float* dst, int nx, int ny, int nz, const float* taps_y_host,
+                                         int ntaps_y, const float* taps_z_host, int ntaps_z, void* stream) {
+  if (!src || !dst || src == dst || !taps_y_host || !taps_z_host) return FSG_E_BADARG;
+  if (nx <= 0 || ny <= 0 || nz <= 0) return FSG_E_BADARG;
+  if (ntaps_y <= 0 || (ntaps_y & 1) == 0 || ntaps_z <= 0 || (ntaps_z & 1) == 0) return FSG_E_BADARG;
+  if ((size_t)nx * ny * nz > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  const int R = ntaps_y >> 1;
+  const bool aligned = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  // one workgroup spans the whole z extent: 32 rows x (nz + halo) floats of LDS
+  if (!aligned || (nz & 3) || ntaps_y != ntaps_z || R < 1 || R > YZ_MAXR || nx > 65535 || nz > 496) return FSG_E_ALIGN;
+  for (int t = 0; t < ntaps_y; ++t)
+    if (taps_y_host[t] != taps_z_host[t]) return FSG_E_ALIGN;
+  Taps T;
+  for (int t = 0; t < MAX_TAPS; ++t) T.w[t] = t < ntaps_y ? taps_y_host[t] : 0.f;
+  hipStream_t st = fsg_stream(stream);
+  switch (R) {
+    case 1: return launch_yz<1>(src, dst, nx, ny, nz, T, st);
+    case 2: return launch_yz<2>(src, dst, nx, ny, nz, T, st);
+    case 3: return launch_yz<3>(src, dst, nx, ny, nz, T, st);
+    case 4: return launch_yz<4>(src, dst, nx, ny, nz, T, st);
+    case 5: return launch_yz<5>(src, dst, nx, ny, nz, T, st);
+    case 6: return launch_yz<6>(src, dst, nx, ny, nz, T, st);
+    case 7: return launch_yz<7>(src, dst, nx, ny, nz, T, st);
+    default: return launch_yz<8>(src, dst, nx, ny, nz, T, st);
+  }
 }

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/fsg_hip.h"
 
+extern int g_tuning_flags;
+
 #define FSG_TRY(expr)        \
   do {                       \
     int rc_ = (expr);        \
@@ -72,6 +74,16 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     for (int axis = 0; axis < 3; ++axis) {
       const int nt = p->blur_ntaps[axis];
       if (nt <= 0) continue;
+      if (axis == 1 && p->blur_ntaps[2] > 0 && !(g_tuning_flags & FSG_TUNE_NO_BLUR_FUSE)) {
+        // y and z passes in one launch (intermediate in LDS); bit-identical to the two single-axis launches
+        int rf = fsg_blur_yz_taps_host_f32(cur, other, n0, n1, n2, p->blur_taps[1], nt, p->blur_taps[2], p->blur_ntaps[2],
+                                           stream);
+        if (rf == 0) {
+          float* t = cur; cur = other; other = t;
+          break;
+        }
+        if (rf != FSG_E_ALIGN) return rf;
+      }
       int rc = fsg_blur_axis_taps_host_f32(cur, other, n0, n1, n2, axis, p->blur_taps[axis], nt, stream);
       if (rc == FSG_E_ALIGN) return FSG_E_ALIGN;  // shape outside the tuned kernels: stage-by-stage path
       FSG_TRY(rc);

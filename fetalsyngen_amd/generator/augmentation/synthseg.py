@@ -57,7 +57,14 @@ class RandResample(RandTransform):
 
     @staticmethod
     def blur(output, stds):
-        for axis in range(3):
+        """x pass, then y and z passes (one fused launch when both are active and the shape allows; same result)."""
+        if stds[0] > 0:
+            output = K.blur_axis(output.contiguous(), 0, T.gaussian_taps(float(stds[0])))
+        if stds[1] > 0 and stds[2] > 0:
+            fused = K.blur_yz(output.contiguous(), T.gaussian_taps(float(stds[1])), T.gaussian_taps(float(stds[2])))
+            if fused is not None:
+                return fused
+        for axis in (1, 2):
             if stds[axis] > 0:
                 output = K.blur_axis(output.contiguous(), axis, T.gaussian_taps(float(stds[axis])))
         return output

@@ -431,6 +431,23 @@ def blur_axis(x, axis: int, taps: np.ndarray, force_generic=False) -> torch.Tens
     return out
 
 
+def blur_yz(x, taps_y: np.ndarray, taps_z: np.ndarray):
+    """Axis-1 then axis-2 blur in one launch (fsg_blur_yz_taps_host_f32); None when the shape / radii are outside the
+    fused kernel's domain (the caller then runs the two single-axis passes)."""
+    _need_gpu(x)
+    nx, ny, nz = _dims3(_f32(x))
+    ty = np.ascontiguousarray(taps_y, dtype=np.float32)
+    tz = np.ascontiguousarray(taps_z, dtype=np.float32)
+    out = torch.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    rc = _lib.load().fsg_blur_yz_taps_host_f32(_p(x), _p(out), nx, ny, nz, ty.ctypes.data_as(fp), len(ty),
+                                               tz.ctypes.data_as(fp), len(tz), _stream(x))
+    if rc == _lib.E_ALIGN:
+        return None
+    _lib.check(rc, "fsg_blur_yz_taps_host_f32")
+    return out
+
+
 def reduce_minmax(x) -> torch.Tensor:
     _need_gpu(x)
     mm = new_minmax(x.device)

@@ -76,6 +76,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_BUFFER_LOADS 64 /* opt in: patch kernel body on raw buffer loads (fewer instructions, slower in r01) */
 #define FSG_TUNE_ROW_ZOOM 256    /* resample + noise (K7): the row-per-wave kernels instead of the tile kernel */
 #define FSG_TUNE_TILE_ZOOM 512   /* every zoom through the tile kernel (default: only the noise epilogues) */
+#define FSG_TUNE_NO_BLUR_FUSE 1024 /* blur: y and z passes as two launches */
 #define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
@@ -208,6 +209,12 @@ int fsg_blur_axis_f32(const float* src, float* dst, int nx, int ny, int nz, int 
  * caller then uses fsg_blur_axis_f32).  Same result contract as fsg_blur_axis_f32. */
 int fsg_blur_axis_taps_host_f32(const float* src, float* dst, int nx, int ny, int nz, int axis,
                                 const float* taps_host, int ntaps, void* stream);
+
+/* y pass then z pass of the same blur in ONE launch (the intermediate volume stays in LDS): bit-identical to
+ * fsg_blur_axis_taps_host_f32(axis 1) followed by (axis 2).  Serves identical taps on both axes (the isotropic blur of
+ * RandResample), radius 1..8, 16-byte aligned volumes, nz % 4 == 0; FSG_E_ALIGN otherwise.  Algorithmic bytes: two passes (16 B/voxel) for 8 B/voxel of HBM traffic. */
+int fsg_blur_yz_taps_host_f32(const float* src, float* dst, int nx, int ny, int nz, const float* taps_y_host, int ntaps_y,
+                              const float* taps_z_host, int ntaps_z, void* stream);
 
 /* ---- K8 stand-alone (synthseg.py:206-235) ------------------------------------------------------ */
 int fsg_add_noise_f32(const float* x, size_t n, const float* noise, uint64_t seed, uint64_t stream_id,

@@ -287,6 +287,26 @@ def test_zoom_tile_kernel_equals_row_kernels(K):
                 assert torch.equal(a, b), (shape, m, key)
 
 
+def test_blur_yz_fused_equals_two_passes(K):
+    """y + z pass in one launch (intermediate in LDS) against the two single-axis launches: bit-identical, for tile-ragged
+    shapes and every radius 1..8; outside its domain (different taps per axis, nz % 4, radius > 8) it declines (None)."""
+    from fetalsyngen_amd import tables as T
+
+    rs = np.random.RandomState(6)
+    for shape in [(8, 64, 64), (5, 40, 72), (3, 33, 20), (2, 100, 132), (4, 32, 256), (2, 70, 384)]:
+        x = dev((rs.rand(*shape) * 255).astype(np.float32))
+        for sg in (0.3, 0.44, 0.9, 1.3, 1.6, 1.77, 2.2, 2.5, 2.66):  # radii 1..8
+            tp = T.gaussian_taps(sg)
+            ref = K.blur_axis(K.blur_axis(x, 1, tp), 2, tp)
+            got = K.blur_yz(x, tp, tp)
+            assert got is not None and torch.equal(got, ref), (shape, sg)
+        assert K.blur_yz(x, T.gaussian_taps(0.9), T.gaussian_taps(1.3)) is None  # different taps per axis: two passes
+    x = dev((rs.rand(4, 16, 30) * 255).astype(np.float32))  # nz % 4 != 0
+    assert K.blur_yz(x, T.gaussian_taps(1.0), T.gaussian_taps(1.0)) is None
+    x = dev((rs.rand(4, 64, 64) * 255).astype(np.float32))  # radius 9
+    assert K.blur_yz(x, T.gaussian_taps(3.0), T.gaussian_taps(1.0)) is None
+
+
 def test_blur_long_kernels(K):
     """Radius 9..64 (BlurCortex draws its sigmas from a gamma distribution, augmentation/artifacts.py:104): the run-time
     radius kernels against the generic kernel and the oracle, including rows shorter than the kernel."""
