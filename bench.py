@@ -58,10 +58,10 @@ def _drop_events(events):
     events.clear()
 
 
-def blur_traffic_per_launch(passes, size):
-    """HBM-side bytes per blur launch from the committed PMC summary (profiles/r*_blur_pmc.json: FETCH_SIZE
+def blur_traffic_per_sample(passes, size):
+    """HBM-side bytes of one sample's blur (x pass + fused y,z pass) from the committed PMC summary (profiles/r*_blur_pmc.json: FETCH_SIZE
     and WRITE_SIZE collected in separate rocprofv3 --pmc passes of the same kernels, gfx950 x2 fetch
-    correction applied), averaged over the (axis, radius) mix this run actually launched."""
+    correction applied), averaged over the radius mix this run actually launched."""
     files = sorted((REPO / "profiles").glob("r*_blur_pmc.json"))
     if not files or not passes:
         return None
@@ -85,13 +85,34 @@ def blur_traffic_per_launch(passes, size):
             if lo_ <= R <= hi_:
                 return pts[lo_] + (pts[hi_] - pts[lo_]) * (R - lo_) / (hi_ - lo_)
 
-    tot, n = 0.0, 0
-    for axis, R in passes:
-        t = lookup("blur_contig_lds<" if axis == 2 else "blur_strided_v4<", R)
-        if t is None:
-            return None
-        tot, n = tot + t, n + 1
-    return round(tot / n)
+    # per blur section: x pass, then the fused y+z launch when both are active with the same radius (<= 8), else two passes
+    tot, nsec = 0.0, 0
+    i = 0
+    while i < len(passes):
+        sec = []
+        while i < len(passes) and (not sec or passes[i][0] > sec[-1][0]):
+            sec.append(passes[i])
+            i += 1
+        byaxis = dict(sec)
+        if 0 in byaxis:
+            t = lookup("blur_strided_v4<", byaxis[0])
+            if t is None:
+                return None
+            tot += t
+        if 1 in byaxis and 2 in byaxis and byaxis[1] == byaxis[2] and byaxis[1] <= 8:
+            t = lookup("blur_yz_fused_kernel<", byaxis[1])
+            if t is None:
+                return None
+            tot += t
+        else:
+            for axis in (1, 2):
+                if axis in byaxis:
+                    t = lookup("blur_contig_lds<" if axis == 2 else "blur_strided_v4<", byaxis[axis])
+                    if t is None:
+                        return None
+                    tot += t
+        nsec += 1
+    return round(tot / max(nsec, 1))
 
 
 def blur_microbench(shape, device, sigma=1.3, reps=20):
@@ -267,17 +288,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     lib = _lib.load()
-    launches, blur_total_ms, passes = 0, 0.0, []
+    sections, blur_total_ms, passes = 0, 0.0, []
     ms = ctypes.c_float()
     for e0, e1, pl in gen.blur_events:
         _lib.check(lib.fsg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "fsg_event_elapsed_ms")
         blur_total_ms += ms.value
-        launches += len(pl)
+        sections += 1
         passes.extend(pl)
     _drop_events(gen.blur_events)
     gen.blur_events = None
-    blur_us = blur_total_ms * 1e3 / max(launches, 1)
-    achieved = 8.0 * nvox / blur_us / 1e3 if launches else 0.0  # GB/s, algorithmic 8 B/voxel/pass
+    # one blur = three axis passes (8 B/voxel/pass, 24 B/voxel for the blur) issued as two launches: the x pass
+    # and the fused y+z pass (the intermediate stays in LDS)
+    npass = len(passes)
+    blur_us = blur_total_ms * 1e3 / max(sections, 1)           # per sample
+    alg_bytes = 8.0 * nvox * npass / max(sections, 1)          # per sample
+    achieved = alg_bytes / blur_us / 1e3 if sections else 0.0  # GB/s
 
     result = {
         "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
@@ -296,12 +321,16 @@ def main():
                    "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation resident in HBM",
                    "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
                    "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams},
-        "roofline": {"bound": "hbm", "kernel": "blur axis pass (fsg_blur_axis_taps_host_f32)",
+        "roofline": {"bound": "hbm",
+                     "kernel": "separable 3-pass blur = x pass (fsg_blur_axis_taps_host_f32) + fused y,z pass "
+                               "(fsg_blur_yz_taps_host_f32), HIP events around both launches of every timed sample",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": blur_traffic_per_launch(passes, args.size),
-                     "us_per_launch": round(blur_us, 2), "launches_timed": launches,
-                     "algorithmic_bytes_per_launch": 8 * nvox},
+                     "traffic": blur_traffic_per_sample(passes, args.size),
+                     "us_per_launch": round(blur_us / 2, 2), "launches_timed": 2 * sections,
+                     "algorithmic_bytes_per_launch": int(alg_bytes / 2),
+                     "per_sample": {"us": round(blur_us, 2), "axis_passes": round(npass / max(sections, 1), 2), "launches": 2,
+                                    "algorithmic_bytes": int(alg_bytes)}},
     }
     if rank == 0:
         if not args.no_microbench:

@@ -85,6 +85,7 @@ for sigma in (0.6, 1.3, 1.77):
     taps = T.gaussian_taps(sigma)
     for axis in range(3):
         timeit(f"blur_axis{axis}_R{len(taps)//2}", lambda: K.blur_axis(img, axis, taps), 8 * N)
+    timeit(f"blur_yz_fused_R{len(taps)//2}", lambda: K.blur_yz(img, taps, taps), 16 * N)
 
 m = args.m
 stds, new, fac, rtabs = T.resample_plan(shape, [0.5] * 3, [0.5 * n / m] * 3, 0.5)
