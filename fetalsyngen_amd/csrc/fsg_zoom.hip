@@ -142,7 +142,8 @@ __device__ __forceinline__ void zoom_emit(const ZoomK& Z, const EpiZ& E, const f
     hi = fmaxf(hi, v);
   } else {
     float t = v / mx;
-    if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (t - mnq) / den;
+    // den == 1 (min == 0: K8 clamps at 0, so this is the usual case): x / 1.0f == x exactly, the division is skipped
+    if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : (t - mnq) / den);
     Z.dst[o] = t;
   }
 }
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float t = v[u] / mx;
-        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (t - mnq) / den;
+        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : (t - mnq) / den);
         v[u] = t;
       }
     }
