@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void label_stats_kernel(const uint8_t* __restr
   }
 }
 
+#ifndef FSG_GMM_GRID
+#define FSG_GMM_GRID 8192
+#endif
+
 inline unsigned grid_for(size_t items, unsigned cap = 4096) {
   size_t b = (items + 255) / 256;
   if (b < 1) b = 1;
@@ -245,7 +249,7 @@ int fsg_gmm_sample_u8x4_mm(const uint8_t* l0, const uint8_t* l1, const uint8_t* 
   if (!l0 || !mus || !sigmas || !out || ntab <= 0 || ntab > 256) return FSG_E_BADARG;
   const uintptr_t al = (uintptr_t)l0 | (uintptr_t)l1 | (uintptr_t)l2 | (uintptr_t)l3;
   if ((al & 3) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
-  hipLaunchKernelGGL(gmm_x4_kernel, dim3(grid_for((n + 3) / 4, 8192)), dim3(256), 0, fsg_stream(stream), l0, l1, l2, l3,
+  hipLaunchKernelGGL(gmm_x4_kernel, dim3(grid_for((n + 3) / 4, FSG_GMM_GRID)), dim3(256), 0, fsg_stream(stream), l0, l1, l2, l3,
                      n, mus, sigmas, ntab, noise, seed, stream_id, out, mm, nmin, nmax);
   FSG_RETURN_LAUNCH();
 }
