@@ -209,3 +209,24 @@ def reset_transform(transform):
     ax[:, :-1] = 0
     ax[:, -1] -= ax[:, -1].mean()
     return RigidTransform(ax)
+
+
+def init_stack_transform(n_slice: int, gap: float, device=None) -> RigidTransform:
+    """Axis-aligned stack: identity orientation, slices `gap` apart, centred (transform.py:372-378)."""
+    ax = torch.zeros((n_slice, 6), dtype=torch.float32)
+    ax[:, -1] = (torch.arange(n_slice, dtype=torch.float32) - (n_slice - 1) / 2.0) * gap
+    return RigidTransform(ax, trans_first=True)
+
+
+def mat_transform_points(mat: torch.Tensor, x: torch.Tensor, trans_first: bool) -> torch.Tensor:
+    """Apply (*,3,4) transforms to (*,3) points: R (x + t) when trans_first, else R x + t (transform.py:393-404)."""
+    R, T = mat[..., :-1], mat[..., -1:]
+    x = x[..., None]
+    x = torch.matmul(R, x + T) if trans_first else torch.matmul(R, x) + T
+    return x[..., 0]
+
+
+def transform_points(transform: RigidTransform, x: torch.Tensor) -> torch.Tensor:
+    """Points (N,3) through N transforms, or (*,3) through one (transform.py:407-414)."""
+    assert x.ndim == 2 and x.shape[-1] == 3
+    return mat_transform_points(transform.matrix(transform.trans_first), x, transform.trans_first)

@@ -92,3 +92,17 @@ def test_grid_resample_tables_match_grid_sample():
                              align_corners=True)[0, 0].numpy()
         got = _apply_tables(x, [_axis_resample_tables(vs[i], res, res_r, nearest) for i in range(3)])
         np.testing.assert_allclose(got, ref, atol=1e-6)
+
+
+def test_point_transforms_and_axis_aligned_stack():
+    st = SV.init_stack_transform(5, 2.0)
+    assert torch.equal(st.axisangle()[:, -1], torch.tensor([-4.0, -2.0, 0.0, 2.0, 4.0])) and torch.all(st.axisangle()[:, :5] == 0)
+    rng = np.random.default_rng(2)
+    ax = torch.from_numpy(np.concatenate([rng.uniform(-1, 1, (6, 3)), rng.uniform(-5, 5, (6, 3))], 1).astype(np.float32))
+    tr = SV.RigidTransform(ax)
+    x = torch.from_numpy(rng.standard_normal((6, 3)).astype(np.float32))
+    y = SV.transform_points(tr, x)
+    back = SV.transform_points(tr.inv(), y)  # (R, t)^-1 = (R^T, -R t) in the translation-first convention
+    assert torch.allclose(back, x, atol=1e-4)
+    m = tr.matrix()
+    assert torch.allclose(SV.mat_transform_points(m, x, True), torch.einsum("nij,nj->ni", m[:, :, :3], x + m[:, :, 3]), atol=1e-5)
