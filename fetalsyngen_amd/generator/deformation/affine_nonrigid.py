@@ -58,6 +58,19 @@ class SpatialDeformation:
         self.nonlin_std_max = nonlin_std_max
         self.device = device
 
+    def _shape_constants(self, shape3):
+        """Per-shape constants of the plan (cached: the plan runs once per sample on the host's critical path)."""
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        hit = cache.get(shape3)
+        if hit is None:
+            shp = np.array(shape3)
+            centre32 = ((shp - 1) / 2).astype(np.float32)
+            room = np.maximum((shp - np.asarray(self.size)).astype(np.float32) / np.float32(2), np.float32(0))
+            hit = cache[shape3] = (shp, centre32, room.astype(np.float64))
+            if len(cache) > 16:
+                cache.pop(next(iter(cache)))
+        return hit
+
     # ---- host: random draws in the reference's order (ref :140-145, :248-263, :284, :303-318) ----
     def plan(self, image_shape, random_shift=True, genparams: dict = {}) -> DeformPlan:
         p = DeformPlan()
@@ -66,7 +79,7 @@ class SpatialDeformation:
             return p
         p.active = True
         p.flip = genparams["flip"] if "flip" in genparams else bool(np.random.rand() < self.flip_prb)
-        shp = np.array(tuple(image_shape)[0:3])
+        shp, centre32, room64 = self._shape_constants(tuple(image_shape)[0:3])
 
         ga = genparams.get("affine", {})
         rot = ga["rotations"] if "rotations" in ga else (
@@ -74,12 +87,10 @@ class SpatialDeformation:
         shr = ga["shears"] if "shears" in ga else 2 * self.max_shear * np.random.rand(3) - self.max_shear
         scl = ga["scalings"] if "scalings" in ga else 1 + (2 * self.max_scaling * np.random.rand(3) - self.max_scaling)
         p.A = torch.from_numpy(make_affine_matrix(rot, shr, scl).astype(np.float32))
-        centre32 = ((shp - 1) / 2).astype(np.float32)
         if random_shift:
             u = torch.rand(3, dtype=torch.float64).numpy()  # float64 draw, always consumed
-            room = np.maximum((shp - np.asarray(self.size)).astype(np.float32) / np.float32(2), np.float32(0))
             # fp32 centre + fp64 shift promotes to float64 in the reference; with no room the shift is exactly 0
-            centre = centre32.astype(np.float64) + (2 * (room.astype(np.float64) * u) - room.astype(np.float64))
+            centre = centre32.astype(np.float64) + (2 * (room64 * u) - room64)
         else:
             centre = centre32
         p.c2 = torch.from_numpy(np.ascontiguousarray(centre))

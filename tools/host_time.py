@@ -8,7 +8,8 @@ from fetalsyngen_amd.data.datasets import SeedBank
 from fetalsyngen_amd.phantom import make_seed_volumes
 from fetalsyngen_amd import sharding
 
-shape = (256,) * 3
+import os
+shape = (int(os.environ.get("FSG_HT_SIZE", "256")),) * 3
 seg, seeds = make_seed_volumes(shape)
 bank = SeedBank(seeds, "cuda:0"); segd = torch.from_numpy(seg).to("cuda:0")
 gen = bench.build_generator(shape, "cuda:0", "device"); gen.prewarm()
