@@ -125,7 +125,7 @@ class RandBiasField(RandTransform):
     @staticmethod
     def tables(plan: BiasPlan, image_size):
         g = plan.grid
-        tabs, new = T.zoom_tables(g.shape, np.array(tuple(image_size)) / np.array(g.shape))
+        tabs, new = T.zoom_tables_between(tuple(g.shape), tuple(int(v) for v in image_size))  # factor = size / grid
         if new != tuple(int(v) for v in image_size):
             raise ValueError("bias grid does not zoom to the image size")
         return tabs

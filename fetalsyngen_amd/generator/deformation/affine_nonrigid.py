@@ -112,17 +112,19 @@ class SpatialDeformation:
     def make_spec(self, plan: DeformPlan, image_shape, flip_in_kernel: bool, arena: T.Arena | None = None):
         """DeformSpec (+ the arena that must be uploaded before launch when one is passed in)."""
         shape = tuple(int(v) for v in tuple(image_shape)[0:3])
-        centre = (np.array(self.size) - 1) / 2
+        centre = self.__dict__.get("_centre")
+        if centre is None:
+            centre = self._centre = (np.array(self.size) - 1) / 2
         field_dev, tabs = None, None
         own = arena is None
         arena = arena or T.Arena()
         pending = None
         if plan.field_small is not None:
             fs = plan.field_small
-            host_tabs, new = T.zoom_tables(fs.shape[:3], np.array(shape) / np.array(fs.shape[:3]))
+            host_tabs, new = T.zoom_tables_between(tuple(fs.shape[:3]), shape)  # factor = shape / coarse shape
             if new != shape:
                 raise ValueError(f"coarse field {tuple(fs.shape[:3])} does not zoom to {shape} (got {new})")
-            tabs = K.DeviceTables(host_tabs, self.device, arena)
+            tabs = K.device_tables_for(host_tabs, self.device)
             pending = (arena.add(fs.numpy()), tuple(fs.shape))
         if own:
             arena.upload(self.device)
@@ -188,9 +190,7 @@ class _SpecBuilder:
         field = None
         if self.pending is not None:
             off, fshape = self.pending
-            n = int(np.prod(fshape))
-            raw = self.arena.dev[off : off + 4 * n]
-            field = raw.view(torch.float32).view(fshape)
+            field = self.arena.f32(off, fshape)
         c2 = self.plan.c2.to(torch.float32).numpy()  # the kernels add it as fp32, like ATen does
         return K.DeformSpec(self.shape, self.plan.A.numpy(), self.centre, c2,
                             self.plan.flip and self.flip_in_kernel, field, self.tabs, device=self.o.device)

@@ -304,21 +304,20 @@ class FetalSynthGen:
             sb = sd.make_spec(dplan, shape, flip_in_kernel=True, arena=arena) if dplan.active else None
             bias_tabs, bias_off = None, None
             if bplan.active:
-                bias_tabs = K.DeviceTables(self.biasfield.tables(bplan, shape), dev, arena)
+                bias_tabs = K.device_tables_for(self.biasfield.tables(bplan, shape), dev)
                 bias_off = arena.add(bplan.grid.numpy())
             rs_tabs = back_tabs = None
             if rplan.active:
                 rs_tabs = K.DeviceTables(rplan.tabs, dev, arena)
-                bt, new = T.zoom_tables(rplan.new_size, 1 / np.asarray(rplan.factors))
-                back_tabs = K.DeviceTables(bt, dev, arena)
+                # zoom-back by 1 / factors, factors = new_size / size (tables.resample_plan): a function of the two shapes
+                bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
+                back_tabs = K.device_tables_for(bt, dev)
             gm_off = None
             if gmm_plan is not None:
                 gm_off = (arena.add(gmm_plan.mus.numpy()), arena.add(gmm_plan.sigmas.numpy()), gmm_plan.mus.numel())
             arena.upload(dev)
 
-            def f32_view(off, shp):
-                n = int(np.prod(shp))
-                return arena.dev[off : off + 4 * n].view(torch.float32).view(tuple(shp))
+            f32_view = arena.f32
 
             # ---------------- device ----------------------------------------------------------
             seed_intensities = {}

@@ -64,8 +64,19 @@ _DEV_TABLES: dict = {}  # (device, id(host table)) -> (device bytes, host table 
 _DEV_TABLES_MAX = 2048
 
 
+_DEV_KEYS: dict = {}
+
+
+def _device_key(device):
+    """Stable string for a device argument (str / torch.device), memoised: this runs a dozen times per sample."""
+    k = _DEV_KEYS.get(device)
+    if k is None:
+        k = _DEV_KEYS[device] = str(device)
+    return k
+
+
 def _device_table(tab, device):
-    key = (str(device), id(tab))
+    key = (_device_key(device), id(tab))
     hit = _DEV_TABLES.get(key)
     if hit is not None and hit[1] is tab:
         return hit[0]
@@ -90,10 +101,24 @@ class DeviceTables:
     def __init__(self, tabs, device, arena: Arena | None = None):
         self.lengths = tuple(len(t) for t in tabs)
         self._dev = [_device_table(t, device) for t in tabs]
+        self.ptrs = tuple(C.c_void_p(d.data_ptr()) for d in self._dev)  # the device copies never move
 
-    @property
-    def ptrs(self):
-        return tuple(C.c_void_p(d.data_ptr()) for d in self._dev)
+
+_DT_CACHE: dict = {}  # (id(host table list), device) -> (DeviceTables, the list kept alive)
+
+
+def device_tables_for(tabs_list, device) -> DeviceTables:
+    """DeviceTables for a table list with a stable identity (tables.zoom_tables_between memoises its lists): one dict hit
+    per call instead of three table look-ups and a fresh pointer tuple."""
+    key = (id(tabs_list), _device_key(device))
+    hit = _DT_CACHE.get(key)
+    if hit is not None and hit[1] is tabs_list:
+        return hit[0]
+    dt = DeviceTables(tabs_list, device)
+    if len(_DT_CACHE) >= 4096:
+        _DT_CACHE.pop(next(iter(_DT_CACHE)))
+    _DT_CACHE[key] = (dt, tabs_list)
+    return dt
 
 
 def new_minmax(device, nmin=1, nmax=1):
@@ -248,9 +273,9 @@ class DeformSpec:
         self.device = device
         d = _lib.Deform()
         d.shape[:] = self.shape
-        d.A[:] = [float(v) for v in np.asarray(A32, dtype=np.float32).reshape(-1)]
-        d.centre[:] = [float(v) for v in np.asarray(centre32, dtype=np.float32)]
-        d.c2[:] = [float(v) for v in np.asarray(c2_32, dtype=np.float32)]
+        d.A[:] = np.asarray(A32, dtype=np.float32).reshape(-1).tolist()
+        d.centre[:] = np.asarray(centre32, dtype=np.float32).tolist()
+        d.c2[:] = np.asarray(c2_32, dtype=np.float32).tolist()
         d.flip = int(bool(flip))
         self._keep = []
         if field_small is not None:

@@ -53,6 +53,17 @@ def zoom_tables(src_shape, factor):
     return tabs, tuple(int(v) for v in new)
 
 
+@lru_cache(maxsize=4096)
+def zoom_tables_between(src_shape: tuple, dst_shape: tuple, inverse_of_down: bool = False):
+    """`zoom_tables` for a factor that is a function of the two shapes alone, memoised on the shapes (three calls per sample):
+    factor = dst / src (coarse grid -> volume: the deformation field, the bias field), or, with `inverse_of_down`,
+    1 / (src / dst) (RandResample's zoom-back: the reciprocal of the down-sampling factors new_size / size)."""
+    src = np.asarray(src_shape)
+    dst = np.asarray(dst_shape)
+    factor = 1 / (src / dst) if inverse_of_down else dst / src
+    return zoom_tables(src_shape, factor)
+
+
 def position_table(pos64: np.ndarray, n_src: int) -> np.ndarray:
     """Table for explicit float64 sample positions along one axis (axis-aligned trilinear gather):
     positions are rounded to fp32 first; outside (0, n_src-1] is marked lo = -1."""
@@ -95,10 +106,14 @@ def _resample_axis_table(n_new: int, n_src: int) -> np.ndarray:
     return tab
 
 
+@lru_cache(maxsize=64)
+def _tap_positions(half: int) -> torch.Tensor:
+    return torch.linspace(-half, half, 2 * half + 1, dtype=torch.float32)
+
+
 @lru_cache(maxsize=256)
 def gaussian_taps(sigma: float) -> np.ndarray:
-    half = int(np.ceil(3 * sigma))
-    t = torch.linspace(-half, half, 2 * half + 1, dtype=torch.float32)
+    t = _tap_positions(int(np.ceil(3 * sigma)))
     g = torch.exp(-((t / sigma) ** 2) / 2)
     return (g / g.sum()).numpy()
 
@@ -202,7 +217,18 @@ class Arena:
                 hv[off : off + arr.nbytes] = arr.view(np.uint8).reshape(-1)
             self.dev = host.to(device, non_blocking=True)
         self.base = self.dev.data_ptr()
+        self.__dict__.pop("_f32", None)
         return self.dev
 
     def ptr(self, off: int) -> int:
         return self.base + off
+
+    def f32(self, off: int, shape) -> torch.Tensor:
+        """float32 view of an uploaded item (offsets are multiples of ALIGN)."""
+        f = self.__dict__.get("_f32")
+        if f is None:
+            f = self._f32 = self.dev.view(torch.float32)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        return f[off >> 2 : (off >> 2) + n].view(tuple(shape))
