@@ -86,6 +86,7 @@ class SamplePlan(C.Structure):
         ("ws_rows", C.c_void_p),
         ("row_stride", C.c_int32),
         ("mm8", C.c_void_p),
+        ("mm8_preset", C.c_int32),
         ("out", C.c_void_p),
         ("ev_blur_begin", C.c_void_p),
         ("ev_blur_end", C.c_void_p),
@@ -148,6 +149,8 @@ SIGNATURES = {
     "fsg_scatter_const_f32": [P, SZ, P, I, F, P],
     "fsg_copy_bytes": [P, P, SZ, P],
     "fsg_zoom_set_tuning": [I, I],
+    "fsg_sample_head_f32": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, C.POINTER(Deform), C.POINTER(Epilogue), P, I, P, P],
+    "fsg_coords_floormin_rest_f32": [C.POINTER(Deform), P, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],

@@ -107,6 +107,54 @@ __device__ __forceinline__ float fsg_randn1(uint64_t seed, uint64_t stream_id, u
   }
 }
 
+// K1 voxel loop shared by gmm_x4_kernel and the fused head of a sample (fsg_deform.hip): workgroup `blk` of `nblk`,
+// tables already in LDS.
+__device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, const uint8_t* __restrict__ l1,
+                                                const uint8_t* __restrict__ l2, const uint8_t* __restrict__ l3, size_t n,
+                                                const float* s_mu, const float* s_sg, const float* __restrict__ noise,
+                                                uint64_t seed, uint64_t stream_id, float* __restrict__ out, unsigned blk,
+                                                unsigned nblk) {
+  const size_t ngrp = (n + 3) >> 2;
+  for (size_t g = (size_t)blk * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)nblk * blockDim.x) {
+    const size_t e = g << 2;
+    uint32_t w = 0;
+    if (e + 3 < n) {
+      w = *reinterpret_cast<const uint32_t*>(l0 + e);
+      if (l1) w += *reinterpret_cast<const uint32_t*>(l1 + e);
+      if (l2) w += *reinterpret_cast<const uint32_t*>(l2 + e);
+      if (l3) w += *reinterpret_cast<const uint32_t*>(l3 + e);
+    } else {
+      for (int q = 0; q < 4 && e + q < n; ++q) {
+        uint32_t b = l0[e + q];
+        if (l1) b += l1[e + q];
+        if (l2) b += l2[e + q];
+        if (l3) b += l3[e + q];
+        w |= (b & 255u) << (8 * q);
+      }
+    }
+    float z[4];
+    if (noise) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) z[q] = (e + q < n) ? noise[e + q] : 0.f;
+    } else {
+      const float4 r = fsg_randn4(seed, stream_id, (uint64_t)g);
+      z[0] = r.x; z[1] = r.y; z[2] = r.z; z[3] = r.w;
+    }
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l = (int)((w >> (8 * q)) & 255u);
+      const float t = s_mu[l] + s_sg[l] * z[q];
+      v[q] = t < 0.f ? 0.f : t;
+    }
+    if (e + 3 < n) {
+      *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int q = 0; q < 4 && e + q < n; ++q) out[e + q] = v[q];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // separable linear interpolation from a small/any grid with per-axis tables, reference order:
 //   x: t = wl*a + wh*b (per y,z corner), then y, then z   (utils/generation.py:376-386)

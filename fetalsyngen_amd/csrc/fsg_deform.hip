@@ -239,11 +239,10 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 // the coarse grid); 3*f2 <= e < 3*f2 + b2 -> x/y-interpolated bias grid.  One thread per entry.  With this
 // buffer the warp / min-max kernels start a row with ONE coalesced load instead of a dependent chain
 // (table entry -> four coarse-grid loads -> LDS).
-__global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, float* __restrict__ rows, int stride) {
+__device__ __forceinline__ void deform_rows_body(const FsgDeformK& D, const EpiK& E, float* __restrict__ rows, int stride,
+                                                 int i, int t) {  // t = (j, e) of x plane i
   const int nf = D.field ? 3 * D.f2 : 0;
   const int need = nf + (E.bias ? E.b2 : 0);
-  const int i = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (j, e) of this x plane
   if (t >= D.n1 * need) return;
   const int j = t / need, e = t - j * need;
   float v;
@@ -270,6 +269,87 @@ __global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, 
   rows[((size_t)i * D.n1 + j) * stride + e] = v;
 }
 
+// Workgroup form of the same values.  The per-entry kernel is bound by dependent round trips, not by bytes: 11 000 workgroups
+// each live for a tap load -> four gathers -> one store, and only 2 048 of them are resident at a time.  Here a workgroup
+// owns one x plane and RB_J consecutive y rows: ONE phase of global loads (the x taps, the two coarse planes they select,
+// the y taps of its rows), then every entry is a y-blend of two LDS values.  Blend order x then y as above: bit-identical.
+constexpr int RB_J = 64;        // y rows per workgroup
+constexpr int RB_SLAB_F = 2048; // floats: f1 * f2 * 3 of the coarse displacement grid
+constexpr int RB_SLAB_B = 256;  // floats: b1 * b2 of the coarse bias grid
+constexpr int RB_NEED = 512;    // entries per row
+
+struct RowsSmem {
+  float sf[RB_SLAB_F];
+  float sb[RB_SLAB_B];
+  int tab[RB_NEED];
+  int4 ty[RB_J];
+  int4 by[RB_J];
+};
+
+__host__ __device__ inline bool rows_block_fits(const FsgDeformK& D, const EpiK& E) {
+  const int nf = D.field ? 3 * D.f2 : 0, nb = E.bias ? E.b2 : 0;
+  return (D.field ? D.f1 * D.f2 * 3 : 0) <= RB_SLAB_F && (E.bias ? E.b1 * E.b2 : 0) <= RB_SLAB_B && nf + nb <= RB_NEED;
+}
+
+__device__ __forceinline__ void deform_rows_block(const FsgDeformK& D, const EpiK& E, float* __restrict__ rows, int stride,
+                                                  int i, int j0, RowsSmem& S) {
+  const int tid = threadIdx.x;
+  const int nf = D.field ? 3 * D.f2 : 0, nb = E.bias ? E.b2 : 0, need = nf + nb;
+  const int slab_f = D.field ? D.f1 * D.f2 * 3 : 0, slab_b = E.bias ? E.b1 * E.b2 : 0;
+  const int jn = min(RB_J, D.n1 - j0);
+  if (tid < jn) {
+    if (D.field) S.ty[tid] = *reinterpret_cast<const int4*>(D.ty + j0 + tid);
+    if (E.bias) S.by[tid] = *reinterpret_cast<const int4*>(E.by + j0 + tid);
+  }
+  if (D.field) {
+    const fsg_tap a = uniform_tap(D.tx, i);
+    const float* g0 = D.field + (size_t)a.lo * slab_f;
+    const float* g1 = D.field + (size_t)a.hi * slab_f;
+    for (int t = tid; t < slab_f; t += 256) S.sf[t] = fsg_mix(a.w_lo, g0[t], a.w_hi, g1[t]);
+  }
+  if (E.bias) {
+    const fsg_tap a = uniform_tap(E.bx, i);
+    const float* g0 = E.bias + (size_t)a.lo * slab_b;
+    const float* g1 = E.bias + (size_t)a.hi * slab_b;
+    for (int t = tid; t < slab_b; t += 256) S.sb[t] = fsg_mix(a.w_lo, g0[t], a.w_hi, g1[t]);
+  }
+  for (int e = tid; e < need; e += 256) {
+    if (e < nf) {
+      const int c = e / D.f2, zs = e - c * D.f2;
+      S.tab[e] = zs * 3 + c;
+    } else {
+      S.tab[e] = e - nf;
+    }
+  }
+  __syncthreads();
+  const int rf = D.f2 * 3;
+  for (int jj = tid >> 6; jj < jn; jj += 4) {
+    float* dst = rows + ((size_t)i * D.n1 + j0 + jj) * stride;
+    for (int e = tid & 63; e < need; e += 64) {
+      const int o = S.tab[e];
+      float v;
+      if (e < nf) {
+        const int4 b = S.ty[jj];
+        v = fsg_mix(__builtin_bit_cast(float, b.z), S.sf[b.x * rf + o], __builtin_bit_cast(float, b.w), S.sf[b.y * rf + o]);
+      } else {
+        const int4 b = S.by[jj];
+        v = fsg_mix(__builtin_bit_cast(float, b.z), S.sb[b.x * E.b2 + o], __builtin_bit_cast(float, b.w),
+                    S.sb[b.y * E.b2 + o]);
+      }
+      dst[e] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void deform_rows_block_kernel(FsgDeformK D, EpiK E, float* __restrict__ rows, int stride) {
+  __shared__ RowsSmem S;
+  deform_rows_block(D, E, rows, stride, blockIdx.y, blockIdx.x * RB_J, S);
+}
+
+__global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, float* __restrict__ rows, int stride) {
+  deform_rows_body(D, E, rows, stride, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // ---- floor(min) of the clamped coordinates with a boundary shortcut --------------------------------------
 // Only floor(min) per axis is consumed downstream (margin subtraction, affine_nonrigid.py:350-358).  The
 // coordinates are clamped to [0, n-1], so as soon as ONE voxel has a coordinate < 1 on an axis, that axis'
@@ -277,23 +357,41 @@ __global__ __launch_bounds__(256) void deform_rows_kernel(FsgDeformK D, EpiK E, 
 // evaluates the six faces only (2.3 % of a 256^3 grid); pass 2 (all voxels) runs only for the rare
 // deformations where some axis is still unresolved -- every block of it first checks the three keys and
 // exits when all are below key(1.0).  The result has the same floor as the exact minimum.
-__global__ __launch_bounds__(256) void coords_faces_min_kernel(FsgDeformK D, int32_t* __restrict__ mm3) {
+constexpr int FACE_STEP = 4;
+__host__ __device__ inline int faces_samples(int n) { return (n - 1 + FACE_STEP - 1) / FACE_STEP + 1; }  // 0, 4, .., n-1
+__host__ __device__ inline int faces_total(int n0, int n1, int n2) {
+  const int m0 = faces_samples(n0), m1 = faces_samples(n1), m2 = faces_samples(n2);
+  return 2 * (m1 * m2 + m0 * m2 + m0 * m1);
+}
+
+__device__ __forceinline__ void coords_faces_min_body(const FsgDeformK& D, int32_t* __restrict__ mm3, float (*red)[4],
+                                                      int blk, int nblk) {
+  // every FACE_STEP-th voxel of each face in both directions, the last index always included (corners and edges are in):
+  // ANY subset of voxels is a valid first pass -- a coordinate < 1 found settles its axis, an axis left open sends the
+  // sample through the exact full pass
   const int n0 = D.n0, n1 = D.n1, n2 = D.n2;
-  const int fa = n1 * n2, fb = n0 * n2, fc = n0 * n1;
+  const int m0 = faces_samples(n0), m1 = faces_samples(n1), m2 = faces_samples(n2);
+  const int fa = m1 * m2, fb = m0 * m2, fc = m0 * m1;
   const int total = 2 * (fa + fb + fc);
   float lo[3] = {INFINITY, INFINITY, INFINITY};
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+  for (int t = blk * blockDim.x + threadIdx.x; t < total; t += nblk * blockDim.x) {
     int i, j, k, u = t;
-    if (u < 2 * fa) { i = (u >= fa) ? n0 - 1 : 0; u %= fa; j = u / n2; k = u - j * n2; }
-    else if ((u -= 2 * fa) < 2 * fb) { j = (u >= fb) ? n1 - 1 : 0; u %= fb; i = u / n2; k = u - i * n2; }
-    else { u -= 2 * fb; k = (u >= fc) ? n2 - 1 : 0; u %= fc; i = u / n1; j = u - i * n1; }
+    if (u < 2 * fa) {
+      i = (u >= fa) ? n0 - 1 : 0; u %= fa; j = u / m2; k = u - j * m2;
+      j = min(j * FACE_STEP, n1 - 1); k = min(k * FACE_STEP, n2 - 1);
+    } else if ((u -= 2 * fa) < 2 * fb) {
+      j = (u >= fb) ? n1 - 1 : 0; u %= fb; i = u / m2; k = u - i * m2;
+      i = min(i * FACE_STEP, n0 - 1); k = min(k * FACE_STEP, n2 - 1);
+    } else {
+      u -= 2 * fb; k = (u >= fc) ? n2 - 1 : 0; u %= fc; i = u / m1; j = u - i * m1;
+      i = min(i * FACE_STEP, n0 - 1); j = min(j * FACE_STEP, n1 - 1);
+    }
     float x, y, z;
     fsg_position(D, i, j, k, x, y, z);
     lo[0] = fminf(lo[0], x);
     lo[1] = fminf(lo[1], y);
     lo[2] = fminf(lo[2], z);
   }
-  __shared__ float red[3][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -307,6 +405,52 @@ __global__ __launch_bounds__(256) void coords_faces_min_kernel(FsgDeformK D, int
     for (int w = 1; w < 4; ++w) v = fminf(v, red[a][w]);
     fsg_atomic_min_key(&mm3[a], v);
   }
+}
+
+__global__ __launch_bounds__(256) void coords_faces_min_kernel(FsgDeformK D, int32_t* __restrict__ mm3) {
+  __shared__ float red[3][4];
+  coords_faces_min_body(D, mm3, red, blockIdx.x, gridDim.x);
+}
+
+// ---- head of a sample as ONE launch ----------------------------------------------------------------------------
+// The GMM draw (K1), the per-row coarse values and the six-face minimum do not depend on one another, and the two small ones
+// cost a launch each mostly for the launch itself (~6 us of dispatch + end-of-kernel write-back against 2-4 us of work).
+// Workgroups [0, nfaces) reduce the faces, [nfaces, nfaces + nrows) fill the rows, the rest draw the intensities (VALU-bound,
+// so the small latency-bound work hides beside it).  The min/max keys must already be initialised (they arrive with the
+// parameter arena): no workgroup of this launch may reset what another one reduces into.
+struct HeadGmm {
+  const uint8_t* l0; const uint8_t* l1; const uint8_t* l2; const uint8_t* l3;
+  size_t n;
+  const float* mus; const float* sigmas; int ntab;
+  const float* noise; uint64_t seed, stream_id;
+  float* out;
+};
+
+// 8 waves/SIMD (<= 64 VGPRs) as the stand-alone GMM kernel has: the face job alone would take 73 and cap the launch at 6
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sample_head_kernel(HeadGmm G, FsgDeformK D, EpiK E, float* __restrict__ rows,
+                                                          int stride, int rows_gx, int nrows, int nfaces,
+                                                          int32_t* __restrict__ mm3) {
+  __shared__ float s_mu[256], s_sg[256];
+  __shared__ float red[3][4];
+  __shared__ RowsSmem S;
+  int b = blockIdx.x;  // workgroup-uniform branches: a workgroup does exactly one of the three jobs
+  if (b < nfaces) {  // the longest dependent chain first
+    coords_faces_min_body(D, mm3, red, b, nfaces);
+    return;
+  }
+  b -= nfaces;
+  if (b < nrows) {
+    deform_rows_block(D, E, rows, stride, b / rows_gx, (b % rows_gx) * RB_J, S);
+    return;
+  }
+  b -= nrows;
+  for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+    s_mu[t] = t < G.ntab ? G.mus[t] : 0.f;
+    s_sg[t] = t < G.ntab ? G.sigmas[t] : 0.f;
+  }
+  __syncthreads();
+  fsg_gmm_x4_loop(G.l0, G.l1, G.l2, G.l3, G.n, s_mu, s_sg, G.noise, G.seed, G.stream_id, G.out, (unsigned)b,
+                  gridDim.x - (unsigned)(nrows + nfaces));
 }
 
 constexpr int WARP_ROWS_PER_WAVE = 4;
@@ -1259,6 +1403,11 @@ int fsg_deform_rows_f32(const fsg_deform* d, const fsg_epilogue* epi, float* row
   if (!rows || row_stride < need) return FSG_E_BADARG;
   if (need == 0) return 0;
   if (D.n0 > 65535) return FSG_E_TOOBIG;
+  if (rows_block_fits(D, E) && !(g_tuning_flags & FSG_TUNE_SPLIT_HEAD)) {
+    const dim3 grid((unsigned)((D.n1 + RB_J - 1) / RB_J), (unsigned)D.n0);
+    hipLaunchKernelGGL(deform_rows_block_kernel, grid, dim3(256), 0, fsg_stream(stream), D, E, rows, row_stride);
+    FSG_RETURN_LAUNCH();
+  }
   const dim3 grid((unsigned)((D.n1 * need + 255) / 256), (unsigned)D.n0);
   hipLaunchKernelGGL(deform_rows_kernel, grid, dim3(256), 0, fsg_stream(stream), D, E, rows, row_stride);
   FSG_RETURN_LAUNCH();
@@ -1288,7 +1437,7 @@ int fsg_coords_floormin_f32(const fsg_deform* d, int32_t* mm3, void* stream) {
   if (rc) return rc;
   if (!mm3) return FSG_E_BADARG;
   hipStream_t st = fsg_stream(stream);
-  const int faces = 2 * (D.n1 * D.n2 + D.n0 * D.n2 + D.n0 * D.n1);
+  const int faces = faces_total(D.n0, D.n1, D.n2);
   int g1 = (faces + 255) / 256;
   if (g1 > 1024) g1 = 1024;
   hipLaunchKernelGGL(coords_faces_min_kernel, dim3(g1), dim3(256), 0, st, D, mm3);
@@ -1304,6 +1453,52 @@ int fsg_coords_floormin_f32(const fsg_deform* d, int32_t* mm3, void* stream) {
     // very large coarse grids: exact per-voxel pass (writes the maxima after the three minima too)
     return FSG_E_TOOBIG;
   }
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream) {
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  if (!mm3) return FSG_E_BADARG;
+  if ((D.field ? 3 * D.f2 : 0) > ROWCAP) return FSG_E_TOOBIG;
+  const int rows = D.n0 * D.n1;
+  int grid = (rows + 7) / 8 < 512 ? (rows + 7) / 8 : 512;
+  const int rpb = (rows + grid - 1) / grid;
+  grid = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(coords_minmax_rows_kernel<true>, dim3(grid), dim3(256), 0, fsg_stream(stream), D, mm3, rpb);
+  FSG_RETURN_LAUNCH();
+}
+
+int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                        const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                        uint64_t stream_id, float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
+                        int row_stride, int32_t* mm3, void* stream) {
+  if (n == 0 || !l0 || !mus || !sigmas || !out || ntab <= 0 || ntab > 256 || !mm3) return FSG_E_BADARG;
+  const uintptr_t al = (uintptr_t)l0 | (uintptr_t)l1 | (uintptr_t)l2 | (uintptr_t)l3;
+  if ((al & 3) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  EpiK E;
+  rc = fill_epilogue(epi, E);
+  if (rc) return rc;
+  const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
+  if (need > 0 && (!rows || row_stride < need)) return FSG_E_BADARG;
+  if ((size_t)D.n0 * D.n1 * D.n2 != n) return FSG_E_BADARG;
+  if ((D.field ? 3 * D.f2 : 0) > ROWCAP) return FSG_E_TOOBIG;
+  if (!rows_block_fits(D, E)) return FSG_E_TOOBIG;
+  const int rows_gx = need > 0 ? (D.n1 + RB_J - 1) / RB_J : 0;
+  const long long nrows = (long long)rows_gx * D.n0;
+  const int faces = faces_total(D.n0, D.n1, D.n2);
+  int nfaces = (faces + 255) / 256;
+  if (nfaces > 1024) nfaces = 1024;
+  size_t ngmm = ((n + 3) / 4 + 255) / 256;
+  if (ngmm > 8192) ngmm = 8192;
+  if (nrows > 1000000) return FSG_E_TOOBIG;
+  HeadGmm G{l0, l1, l2, l3, n, mus, sigmas, ntab, noise, seed, stream_id, out};
+  hipLaunchKernelGGL(sample_head_kernel, dim3((unsigned)(nrows + nfaces + ngmm)), dim3(256), 0, fsg_stream(stream), G, D,
+                     E, rows, row_stride, rows_gx > 0 ? rows_gx : 1, (int)nrows, nfaces, mm3);
   FSG_RETURN_LAUNCH();
 }
 

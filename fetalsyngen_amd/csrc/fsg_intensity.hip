@@ -69,45 +69,7 @@ __global__ __launch_bounds__(256) void gmm_x4_kernel(const uint8_t* __restrict__
   if (mm && blockIdx.x == 0 && (int)threadIdx.x < nmin + nmax)
     mm[threadIdx.x] = (int)threadIdx.x < nmin ? fsg_f2key(INFINITY) : fsg_f2key(-INFINITY);
   __syncthreads();
-  const size_t nblk = (n + 3) >> 2;
-  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < nblk; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t e = g << 2;
-    uint32_t w = 0;
-    if (e + 3 < n) {
-      w = *reinterpret_cast<const uint32_t*>(l0 + e);
-      if (l1) w += *reinterpret_cast<const uint32_t*>(l1 + e);
-      if (l2) w += *reinterpret_cast<const uint32_t*>(l2 + e);
-      if (l3) w += *reinterpret_cast<const uint32_t*>(l3 + e);
-    } else {
-      for (int q = 0; q < 4 && e + q < n; ++q) {
-        uint32_t b = l0[e + q];
-        if (l1) b += l1[e + q];
-        if (l2) b += l2[e + q];
-        if (l3) b += l3[e + q];
-        w |= (b & 255u) << (8 * q);
-      }
-    }
-    float z[4];
-    if (noise) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) z[q] = (e + q < n) ? noise[e + q] : 0.f;
-    } else {
-      const float4 r = fsg_randn4(seed, stream_id, (uint64_t)g);
-      z[0] = r.x; z[1] = r.y; z[2] = r.z; z[3] = r.w;
-    }
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int l = (int)((w >> (8 * q)) & 255u);
-      const float t = s_mu[l] + s_sg[l] * z[q];
-      v[q] = t < 0.f ? 0.f : t;
-    }
-    if (e + 3 < n) {
-      *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      for (int q = 0; q < 4 && e + q < n; ++q) out[e + q] = v[q];
-    }
-  }
+  fsg_gmm_x4_loop(l0, l1, l2, l3, n, s_mu, s_sg, noise, seed, stream_id, out, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed,

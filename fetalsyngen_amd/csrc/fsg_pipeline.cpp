@@ -24,35 +24,57 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   if (n > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
 
-  // K1: GMM draw -> ws0; the same launch resets every min/max key of the sample:
+  const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
+  bool head_done = false;
+  fsg_deform dh = p->deform;
+  if (p->deform_active && p->mm8_preset && p->ws_rows && !(g_tuning_flags & FSG_TUNE_SPLIT_HEAD)) {
+    // K1 + per-row coarse values + six-face minimum in one launch (keys arrive initialised with the parameters)
+    const int need = 3 * dh.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
+    if (need > 0 && need <= p->row_stride) {
+      dh.rows = nullptr;
+      dh.row_stride = 0;
+      int rc = fsg_sample_head_f32(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
+                                   p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
+                                   p->ws_rows, p->row_stride, p->mm8, stream);
+      if (rc == 0) head_done = true;
+      else if (rc != FSG_E_TOOBIG && rc != FSG_E_ALIGN) return rc;
+    }
+  }
+  // K1: GMM draw -> ws0; the same launch resets every min/max key of the sample (unless they arrived initialised):
   // [min x,y,z | zoom min] [zoom max | 3 unused]
-  FSG_TRY(fsg_gmm_sample_u8x4_mm(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n,
-                                 p->mus, p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0,
-                                 p->mm8, 4, 4, stream));
+  if (!head_done)
+    FSG_TRY(fsg_gmm_sample_u8x4_mm(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n,
+                                   p->mus, p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0,
+                                   p->mm8_preset ? nullptr : p->mm8, 4, 4, stream));
   float* cur = p->ws0;
   float* other = p->ws1;
-  const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
 
   if (p->deform_active) {
     // K2/K3: coarse rows, floor(min) margins; K4(+K5): fused warp of the image and the labels -> ws1
     if (!p->seg_in || !p->seg_out) return FSG_E_BADARG;
     fsg_deform d = p->deform;
     const int need = 3 * d.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
-    if (p->ws_rows && need > 0 && need <= p->row_stride) {
-      d.rows = nullptr;
-      d.row_stride = 0;
-      FSG_TRY(fsg_deform_rows_f32(&d, &p->epi, p->ws_rows, p->row_stride, stream));
+    if (head_done) {
       d.rows = p->ws_rows;
       d.row_stride = p->row_stride;
+      FSG_TRY(fsg_coords_floormin_rest_f32(&d, p->mm8, stream));
     } else {
-      d.rows = nullptr;
-      d.row_stride = 0;
+      if (p->ws_rows && need > 0 && need <= p->row_stride) {
+        d.rows = nullptr;
+        d.row_stride = 0;
+        FSG_TRY(fsg_deform_rows_f32(&d, &p->epi, p->ws_rows, p->row_stride, stream));
+        d.rows = p->ws_rows;
+        d.row_stride = p->row_stride;
+      } else {
+        d.rows = nullptr;
+        d.row_stride = 0;
+      }
+      int rc = fsg_coords_floormin_f32(&d, p->mm8, stream);
+      if (rc == FSG_E_TOOBIG) {  // coarse grid beyond the row kernels: exact min/max (6 keys) into a side buffer
+        return FSG_E_TOOBIG;     // the Python orchestration handles this rare configuration stage by stage
+      }
+      FSG_TRY(rc);
     }
-    int rc = fsg_coords_floormin_f32(&d, p->mm8, stream);
-    if (rc == FSG_E_TOOBIG) {  // coarse grid beyond the row kernels: exact min/max (6 keys) into a side buffer
-      return FSG_E_TOOBIG;     // the Python orchestration handles this rare configuration stage by stage
-    }
-    FSG_TRY(rc);
     FSG_TRY(fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream));
     float* t = cur; cur = other; other = t;
   } else {

@@ -30,6 +30,11 @@ from .deformation.affine_nonrigid import SpatialDeformation
 from .intensity.rand_gmm import ImageFromSeeds
 
 
+# [+inf x4 | -inf x4] as the order-preserving int32 keys of fsg_minmax_init (csrc/fsg_common.h: fsg_f2key)
+_MM8_INIT = np.array([0x7F800000] * 4 + [-2139095041] * 4, dtype=np.int32)
+_MM8_INIT.setflags(write=False)
+
+
 class FetalSynthGen:
     def __init__(
         self,
@@ -117,7 +122,7 @@ class FetalSynthGen:
         return ws
 
     def _run_native(self, shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev, bias_tabs,
-                    rplan, rs_tabs, back_tabs, nplan, scale01):
+                    rplan, rs_tabs, back_tabs, nplan, scale01, mm8_ptr=None):
         """Fill a fsg_sample_plan and enqueue the whole sample with one call.  Returns (image, labels), or None
         when the configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
         import ctypes as C
@@ -178,7 +183,10 @@ class FetalSynthGen:
         p.ws0, p.ws1, p.ws_low = ws["ws0"].data_ptr(), ws["ws1"].data_ptr(), ws["low"].data_ptr()
         if ws["rows"] is not None:
             p.ws_rows, p.row_stride = ws["rows"].data_ptr(), ws["stride"]
-        p.mm8 = ws["mm8"].data_ptr()
+        if mm8_ptr is not None:
+            p.mm8, p.mm8_preset = mm8_ptr, 1
+        else:
+            p.mm8 = ws["mm8"].data_ptr()
         p.out = out.data_ptr()
         if self.blur_events is not None and rplan.active:  # (begin, end, n_passes) appended per sample
             lib = _lib.load()
@@ -312,6 +320,7 @@ class FetalSynthGen:
                 # zoom-back by 1 / factors, factors = new_size / size (tables.resample_plan): a function of the two shapes
                 bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
                 back_tabs = K.device_tables_for(bt, dev)
+            mm_off = arena.add(_MM8_INIT)  # the sample's min/max keys arrive initialised with its parameters
             gm_off = None
             if gmm_plan is not None:
                 gm_off = (arena.add(gmm_plan.mus.numpy()), arena.add(gmm_plan.sigmas.numpy()), gmm_plan.mus.numel())
@@ -332,7 +341,7 @@ class FetalSynthGen:
             if (self.native_pipeline and label_parts is not None and image is None and not has_art
                     and segmentation_u8 is None):
                 native = self._run_native(shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev,
-                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01)
+                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01, arena.ptr(mm_off))
                 if native is not None:
                     return native[0], native[1], None, self._params(selected_seeds, seed_intensities, dplan, g, bplan,
                                                                     rplan, nplan, {})

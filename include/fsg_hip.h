@@ -78,6 +78,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_TILE_ZOOM 512   /* every zoom through the tile kernel (default: only the noise epilogues) */
 #define FSG_TUNE_NO_BLUR_FUSE 1024 /* blur: y and z passes as two launches */
 #define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
+#define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
 
@@ -356,6 +357,16 @@ int fsg_scatter_const_f32(float* out, size_t n, const long long* idx, int k, flo
  * the reference's order).  Workspaces are caller-owned and may be reused by the next call on the same stream.
  * Returns FSG_E_ALIGN / FSG_E_TOOBIG for configurations the fused kernels do not cover (the caller then issues
  * the entry points above one by one). */
+/* Head of a sample as ONE launch: the GMM draw (as fsg_gmm_sample_u8x4), the per-row coarse values (as
+ * fsg_deform_rows_f32) and the six-face pass of fsg_coords_floormin_f32 share no data, so their workgroups run side by side.
+ * mm3 must already hold initialised keys (fsg_minmax_init, or key values uploaded with the parameters): nothing in this
+ * launch resets them.  fsg_coords_floormin_rest_f32 is the conditional full pass that completes the floor(min) keys. */
+int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
+                        const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
+                        uint64_t stream_id, float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
+                        int row_stride, int32_t* mm3, void* stream);
+int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream);
+
 typedef struct fsg_sample_plan {
   int32_t shape[3];
   /* K1 */
@@ -391,6 +402,8 @@ typedef struct fsg_sample_plan {
   float* ws_rows;                /* shape[0]*shape[1]*row_stride floats, or NULL                              */
   int32_t row_stride;
   int32_t* mm8;                  /* 8 x int32                                                                 */
+  int32_t mm8_preset;            /* 1: the keys already hold [+inf x4 | -inf x4] (uploaded with the parameters): no reset
+                                  *    launch-side, and the head of the sample runs as one launch (fsg_sample_head_f32)  */
   float* out;                    /* shape[] floats                                                            */
   void* ev_blur_begin;           /* optional hipEvent_t pair recorded around the blur passes (fsg_event_*)     */
   void* ev_blur_end;

@@ -794,6 +794,34 @@ def test_native_pipeline_equals_stagewise(K, rng_mode, prob):
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
 
 
+def test_fused_sample_head_equals_split_launches(K):
+    """The head of a sample as one launch (GMM draw + per-row coarse values + six-face minimum, keys uploaded initialised)
+    against the same three jobs as separate launches with a launch-side key reset (FSG_TUNE_SPLIT_HEAD): images, labels
+    bit-identical, for cubic / ragged shapes, both RNG modes, with and without the bias field."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    lib = _lib.load()
+    for shape in ((48, 40, 32), (33, 50, 44), (64, 64, 64)):
+        seg, seeds = make_seed_volumes(shape, 2)
+        bank, segd = SeedBank(seeds, DEV), dev(seg)
+        for rng_mode in ("device", "reference"):
+            gen = make_generator(shape, DEV, rng=rng_mode, prob=0.7, nonlin_scale=(0.1, 0.25), bf_scale=(0.05, 0.15))
+            for seed in range(5):
+                res = []
+                for flag in (0, 2048):
+                    prev = lib.fsg_set_tuning(flag)
+                    try:
+                        np.random.seed(seed)
+                        torch.manual_seed(seed)
+                        out, lab, _, _ = gen._pipeline(None, segd, bank, {}, scale01=True)
+                        res.append((out.clone(), lab.clone()))
+                    finally:
+                        lib.fsg_set_tuning(prev)
+                assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (shape, rng_mode, seed)
+
+
 # ---- BASELINE.json configs as parity cases ------------------------------------------------------------
 def test_config1_sta21_128_on_gpu(K, golden):
     """BASELINE config 1 (sub-sta21 at 128^3, seed 0, YAML probabilities): the HIP path against what the real
