@@ -129,16 +129,20 @@ def _can_pin() -> bool:
 
 
 class _StagingRing:
-    """Pinned host slots for the parameter arenas of consecutive samples.  A slot is rewritten by the host only after the
-    event recorded behind its copy kernel has completed (the host runs ahead of the GPU by design)."""
+    """Pinned host slots for the parameter arenas of consecutive samples.  A slot is rewritten by the host only after an
+    event recorded behind its copy kernel has completed (the host runs ahead of the GPU by design).  An event record is a
+    barrier packet in the launch queue (~5.5 us of bubble), so ONE event covers a group of GROUP consecutive slots: it is
+    recorded behind the copy of the group's last slot, and a slot of that group is reused (a full lap later) only once it
+    has completed."""
 
     SLOT = 1 << 16
     SLOTS = 32
+    GROUP = 8
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.buf = torch.empty((self.SLOTS, self.SLOT), dtype=torch.uint8, pin_memory=True)
-        self.events = [None] * self.SLOTS
+        self.events = [None] * (self.SLOTS // self.GROUP)
         self.next = 0
         self.lock = threading.Lock()
 
@@ -150,15 +154,18 @@ class _StagingRing:
         with self.lock:
             slot = self.next
             self.next = (slot + 1) % self.SLOTS
-        ev = self.events[slot]
+        ev = self.events[slot // self.GROUP]  # recorded behind this group's last copy of the previous lap
         if ev is not None:
             ev.synchronize()
         return slot, self.buf[slot]
 
     def release(self, slot):
-        ev = self.events[slot]
+        if slot % self.GROUP != self.GROUP - 1:
+            return
+        g = slot // self.GROUP
+        ev = self.events[g]
         if ev is None:
-            ev = self.events[slot] = torch.cuda.Event()
+            ev = self.events[g] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
 
 
@@ -168,10 +175,13 @@ _RINGS: dict = {}
 def _staging_ring(device):
     if os.environ.get("FSG_ARENA_MEMCPY", "0") == "1":
         return None
-    key = str(torch.device(device))
+    dev = torch.device(device)
+    idx = torch.cuda.current_device() if dev.index is None else dev.index
+    # one ring per launch stream: a group's event must sit behind every copy of the group
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
     ring = _RINGS.get(key)
     if ring is None:
-        ring = _RINGS[key] = _StagingRing(device)
+        ring = _RINGS[key] = _StagingRing(dev)  # kept for the life of the process: copies may still be reading it
     return ring
 
 
