@@ -20,6 +20,26 @@ def test_zoom_table_matches_oracle(n_src, n_dst):
     assert tab.dtype.itemsize == 16
 
 
+def test_memoised_zoom_table_lists_are_the_plain_ones():
+    """tables.zoom_tables_between (memoised on the two shapes; three calls per sample on the host's critical path) returns
+    the very table objects of zoom_tables with the factor written out as the call sites used to: shape / coarse shape for
+    the deformation and bias grids, 1 / (new_size / size) for RandResample's zoom-back."""
+    from fetalsyngen_amd import tables as T
+
+    rs = np.random.RandomState(0)
+    for _ in range(100):
+        size = tuple(int(v) for v in rs.randint(20, 300, 3))
+        small = tuple(int(v) for v in np.maximum(np.round(rs.uniform(0.03, 0.2) * np.array(size)), 1).astype(int))
+        a, na = T.zoom_tables(small, np.array(size) / np.array(small))
+        b, nb = T.zoom_tables_between(small, size)
+        assert na == nb and all(x is y for x, y in zip(a, b))
+        _stds, ns, fac, _tabs = T.resample_plan(size, [0.5] * 3, rs.uniform(0.5, 1.5, 3), 0.3)
+        a, na = T.zoom_tables(ns, 1 / np.asarray(fac))
+        b, nb = T.zoom_tables_between(tuple(ns), size, True)
+        assert na == nb and all(x is y for x, y in zip(a, b)), (size, ns)
+    assert T.zoom_tables_between((5, 6, 7), (50, 60, 70))[0] is T.zoom_tables_between((5, 6, 7), (50, 60, 70))[0]
+
+
 def test_gaussian_taps_golden(golden):
     g = golden("gauss_taps")
     for i, s in enumerate(g["sigma"]):
