@@ -180,6 +180,41 @@ def gmm_sample_parts(parts, mus, sigmas, noise=None, seed=0, stream_id=0) -> tor
     return out
 
 
+def sample_head(parts, mus, sigmas, spec: "DeformSpec", bias=None, bias_tabs=None, noise=None, seed=0, stream_id=0,
+                mm3=None):
+    """Head of a sample as one launch (fsg_sample_head_f32): the GMM draw of `gmm_sample_parts`, the per-row coarse values of
+    `DeformSpec.prepare_rows` and the first floor(min) pass of `coords_floormin`.  `mm3` must hold initialised keys
+    (`new_minmax(dev, 3, 0)` when omitted); `coords_floormin_rest` completes them.  Returns (image, mm3); the rows are
+    attached to `spec` as `prepare_rows` would."""
+    parts = [p for p in parts if p is not None]
+    if not 1 <= len(parts) <= 4:
+        raise ValueError("1..4 label volumes expected")
+    _need_gpu(*parts, mus, sigmas, noise)
+    out = torch.empty(parts[0].shape, dtype=F32, device=parts[0].device)
+    if mm3 is None:
+        mm3 = new_minmax(out.device, 3, 0)
+    need = 3 * int(spec.c.field_dims[2]) + (int(bias.shape[2]) if bias is not None else 0)
+    stride = (max(need, 1) + 3) // 4 * 4
+    rows = torch.empty(spec.shape[0] * spec.shape[1] * stride, dtype=F32, device=out.device)
+    epi = _epilogue(None, bias, bias_tabs, spec.shape)
+    spec.c.rows, spec.c.row_stride = None, 0
+    ptrs = [_p(p) for p in parts] + [C.c_void_p(0)] * (4 - len(parts))
+    _lib.check(_lib.load().fsg_sample_head_f32(*ptrs, out.numel(), _p(mus), _p(sigmas), int(mus.numel()), _p(noise), seed,
+                                               stream_id, _p(out), C.byref(spec.c), C.byref(epi), _p(rows), stride,
+                                               _p(mm3), _stream(out)), "fsg_sample_head_f32")
+    spec.c.rows, spec.c.row_stride = rows.data_ptr(), stride
+    spec._keep.append(rows)
+    spec._rows_bias = int(bias.shape[2]) if bias is not None else 0
+    return out, mm3
+
+
+def coords_floormin_rest(spec: "DeformSpec", mm3) -> torch.Tensor:
+    """Conditional full pass that completes the floor(min) keys after `sample_head` (fsg_coords_floormin_rest_f32)."""
+    _lib.check(_lib.load().fsg_coords_floormin_rest_f32(C.byref(spec.c), _p(mm3), _stream(mm3)),
+               "fsg_coords_floormin_rest_f32")
+    return mm3
+
+
 def label_stats(labels_u8, values, nlabels: int):
     """(count int64[nlabels], mean f64, var f64) per label -- wave-level reductions on the device."""
     _need_gpu(labels_u8, values)

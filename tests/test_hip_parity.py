@@ -794,6 +794,43 @@ def test_native_pipeline_equals_stagewise(K, rng_mode, prob):
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
 
 
+def test_sample_head_entry_equals_its_three_parts(K, golden):
+    """fsg_sample_head_f32 through the C ABI against fsg_gmm_sample_u8x4 + fsg_deform_rows_f32 + fsg_coords_floormin_f32:
+    image and rows bit-identical; keys have the golden floors once fsg_coords_floormin_rest_f32 has run (including the
+    engineered golden case whose minima are far from 0, where that pass is the one that settles them)."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+    from fetalsyngen_amd import tables as T
+
+    g = golden("deform_image")
+    rs = np.random.RandomState(8)
+    for i in range(int(g["ncases"])):
+        spec, shape = _spec_from_golden(K, g, i)
+        if int(spec.c.field_dims[2]) == 0:
+            continue  # the head needs at least one row entry
+        seg, seeds = make_seed_volumes(shape, 3)
+        parts = SeedBank(seeds, DEV).parts({1: 1, 2: 1, 3: 1, 4: 1})
+        mus = dev((25 + 200 * rs.rand(50)).astype(np.float32))
+        sig = dev((5 + 20 * rs.rand(50)).astype(np.float32))
+        bsz = (2, 3, 2)
+        bias = dev(rs.randn(*bsz).astype(np.float32))
+        bt, _ = T.zoom_tables_between(bsz, shape)
+        btabs = K.DeviceTables(bt, DEV)
+        img, mm3 = K.sample_head(parts, mus, sig, spec, bias, btabs, seed=5, stream_id=1)
+        rows_head = spec._keep[-1].clone()
+        K.coords_floormin_rest(spec, mm3)
+        assert [int(np.floor(K.key_to_float(k))) for k in host(mm3)[:3]] == list(g[f"margins_{i}"][:3]), i
+        ref_img = K.gmm_sample_parts(parts, mus, sig, seed=5, stream_id=1)
+        spec2, _ = _spec_from_golden(K, g, i)
+        spec2.prepare_rows(bias, btabs)
+        need = 3 * int(spec.c.field_dims[2]) + bsz[2]
+        a = rows_head.view(shape[0] * shape[1], -1)[:, :need]
+        b = spec2._keep[-1].view(shape[0] * shape[1], -1)[:, :need]
+        assert torch.equal(img, ref_img) and torch.equal(a, b), i
+        mm_ref = K.coords_floormin(spec2)
+        assert [int(np.floor(K.key_to_float(k))) for k in host(mm_ref)[:3]] == list(g[f"margins_{i}"][:3]), i
+
+
 def test_fused_sample_head_equals_split_launches(K):
     """The head of a sample as one launch (GMM draw + per-row coarse values + six-face minimum, keys uploaded initialised)
     against the same three jobs as separate launches with a launch-side key reset (FSG_TUNE_SPLIT_HEAD): images, labels
