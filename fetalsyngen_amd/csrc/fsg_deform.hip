@@ -770,6 +770,11 @@ __device__ __forceinline__ void warp_emit_buf(const FsgDeformK& D, const EpiK& E
 // by one wave is an L1 hit for the others.  Same per-voxel arithmetic as the row kernel (warp_emitN).
 constexpr int PATCH = 4;
 constexpr int PATCH_ROWCAP = 128;
+#ifndef FSG_PATCH_NQ
+#define FSG_PATCH_NQ 1
+#endif
+constexpr int PATCH_NQ = FSG_PATCH_NQ;  // 64-voxel chunks per lane and lockstep step (2: 174 us against 135 us -- the L1 working set doubles)
+constexpr int PATCH_TZCAP = 512;  // z extent whose taps are staged in LDS (2 x 8 KB)
 
 template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST, bool BUF>
 __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
@@ -778,6 +783,16 @@ __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const
                                                           const LT* __restrict__ src_nn, LT* __restrict__ out_nn,
                                                           EpiK E) {
   __shared__ float sm_all[PATCH * PATCH][PATCH_ROWCAP];
+  // the z taps of the whole row (displacement and bias grids), staged once per workgroup: read from the tables inside
+  // the chunk loop they put a dependent global round trip in front of every chunk's gathers
+  __shared__ int4 s_tz[PATCH_TZCAP], s_bz[PATCH_TZCAP];
+  const bool taps_lds = D.n2 <= PATCH_TZCAP;
+  if (taps_lds) {
+    for (int t = threadIdx.x; t < D.n2; t += 1024) {
+      if (D.field) s_tz[t] = *reinterpret_cast<const int4*>(D.tz + t);
+      if (E.bias) s_bz[t] = *reinterpret_cast<const int4*>(E.bz + t);
+    }
+  }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tiles_j = (D.n1 + PATCH - 1) / PATCH;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const
     const fsg_tap abx = (onfly && E.bias) ? uniform_tap(E.bx, i) : none;
     stage_row(D, E, i, j, nf, need, ax, abx, sm, lane);
   }
-  wave_lds_sync();
+  __syncthreads();  // rows are wave-private, the z taps were written by every wave
   const size_t row = ((size_t)i * D.n1 + j) * D.n2;
   const unsigned nvox = (unsigned)D.n0 * (unsigned)D.n1 * (unsigned)D.n2;
   WarpBuf B;
@@ -804,23 +819,41 @@ __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const
   B.sy = (unsigned)D.n2;
   B.sx = (unsigned)D.n1 * (unsigned)D.n2;
   B.dx_bytes = D.flip ? -(int)(B.sx * 4u) : (int)(B.sx * 4u);
-  for (int kb = 0; kb < D.n2; kb += FSG_WAVE) {
-    const int kk = kb + lane;
-    const int k = min(kk, D.n2 - 1);
+  auto tap_at = [&](const int4* lds, const fsg_tap* tab, bool on, int k) {
     // NB: written as `if`, not `cond ? table[k] : none`: the ternary makes hipcc scalarise the 16-byte entry
     // into eight branchy dword loads (+35 % kernel time, measured)
-    fsg_tap c = none, cb = none;
-    if (D.field) c = D.tz[k];
-    if (E.bias) cb = E.bz[k];
-    if (BUF) {
+    fsg_tap c = none;
+    if (on) {
+      if (taps_lds) { const int4 v = lds[k]; c = fsg_tap{v.x, v.y, __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)}; }
+      else c = tab[k];
+    }
+    return c;
+  };
+  if (BUF) {
+    for (int kb = 0; kb < D.n2; kb += FSG_WAVE) {
+      const int kk = kb + lane;
+      const int k = min(kk, D.n2 - 1);
+      const fsg_tap c = tap_at(s_tz, D.tz, D.field != nullptr, k), cb = tap_at(s_bz, E.bz, E.bias != nullptr, k);
       warp_emit_buf<LT, HAS_LIN, HAS_NN, FAST>(D, E, m, B, sm, nf, i, j, k, live_row && kk < D.n2, c, cb, row, out_lin,
                                                out_nn);
-    } else if (live_row) {
-      const fsg_tap ck[4] = {c, none, none, none}, cbk[4] = {cb, none, none, none};
-      warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, 1>(D, E, m, sm, nf, i, j, kk, ck, cbk, row, src_lin, out_lin, src_nn,
-                                                  out_nn);
+      __syncthreads();  // keep the 16 waves on the same z chunk: bounded L1 working set, shared misses
     }
-    __syncthreads();  // keep the 16 waves on the same z chunk: bounded L1 working set, shared misses
+  } else {
+    // PATCH_NQ chunks of 64 voxels per step and lane: all their gathers are in flight before the first blend
+    for (int kb = 0; kb < D.n2; kb += PATCH_NQ * FSG_WAVE) {
+      const int kk = kb + lane;
+      fsg_tap ck[4] = {none, none, none, none}, cbk[4] = {none, none, none, none};
+#pragma unroll
+      for (int q = 0; q < PATCH_NQ; ++q) {
+        const int k = min(kk + 64 * q, D.n2 - 1);
+        ck[q] = tap_at(s_tz, D.tz, D.field != nullptr, k);
+        cbk[q] = tap_at(s_bz, E.bz, E.bias != nullptr, k);
+      }
+      if (live_row)
+        warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, PATCH_NQ>(D, E, m, sm, nf, i, j, kk, ck, cbk, row, src_lin, out_lin, src_nn,
+                                                           out_nn);
+      __syncthreads();  // keep the 16 waves on the same z chunks: bounded L1 working set, shared misses
+    }
   }
 }
 
