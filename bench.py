@@ -205,8 +205,8 @@ def cpu_baseline(shape, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--rng", default="device", choices=["device", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
