@@ -306,6 +306,7 @@ def main():
     alg_bytes = 8.0 * nvox * npass / max(sections, 1)          # per sample
     achieved = alg_bytes / blur_us / 1e3 if sections else 0.0  # GB/s
 
+    traffic_sample = blur_traffic_per_sample(passes, args.size)  # HBM bytes of the two launches (committed PMC table)
     result = {
         "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
         "value": round(world * args.steps / dt, 3),
@@ -328,11 +329,11 @@ def main():
                                "(fsg_blur_yz_taps_host_f32), HIP events around both launches of every timed sample",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": blur_traffic_per_sample(passes, args.size),
+                     "traffic": (None if traffic_sample is None else int(traffic_sample / 2)),  # per launch, like achieved
                      "us_per_launch": round(blur_us / 2, 2), "launches_timed": 2 * sections,
                      "algorithmic_bytes_per_launch": int(alg_bytes / 2),
                      "per_sample": {"us": round(blur_us, 2), "axis_passes": round(npass / max(sections, 1), 2), "launches": 2,
-                                    "algorithmic_bytes": int(alg_bytes)}},
+                                    "algorithmic_bytes": int(alg_bytes), "traffic": traffic_sample}},
     }
     if rank == 0:
         if not args.no_microbench:
