@@ -16,12 +16,17 @@ from .. import sharding
 
 
 class HostStager:
-    def __init__(self, shape, device, depth: int = 3, label_dtype=torch.int64):
+    """Ring of pinned host slots.  `depth` samples may be in flight (submitted, not collected); `keep` more
+    slots stay untouched behind them, so the views `collect` hands out remain valid until `keep` further
+    samples have been collected (default 2: the sample just yielded and the one before it)."""
+
+    def __init__(self, shape, device, depth: int = 3, label_dtype=torch.int64, keep: int = 2):
         self.device = torch.device(device)
         self.depth = depth
+        self.keep = max(int(keep), 1)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = []
-        for _ in range(depth):
+        for _ in range(depth + self.keep):
             self.slots.append({
                 "image": torch.empty((1, *shape), dtype=torch.float32, pin_memory=True),
                 "label": torch.empty((1, *shape), dtype=label_dtype, pin_memory=True),
@@ -37,12 +42,14 @@ class HostStager:
         slot = self.slots[slot_id]
         if slot["busy"]:
             raise RuntimeError("HostStager ring overrun: collect() a ticket before submitting more than `depth`")
-        self._next = (self._next + 1) % self.depth
+        self._next = (self._next + 1) % len(self.slots)
+        # the dtype conversion runs on the PRODUCING stream (the caching allocator then knows who reads
+        # `label_dev`); the copy stream only ever touches tensors that carry a record_stream mark
+        lab = label_dev if label_dev.dtype == self.label_dtype else label_dev.to(self.label_dtype)
         produced = torch.cuda.Event()
         produced.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(produced)
-            lab = label_dev if label_dev.dtype == self.label_dtype else label_dev.to(self.label_dtype)
             slot["image"].view(image_dev.shape).copy_(image_dev, non_blocking=True)
             slot["label"].view(lab.shape).copy_(lab, non_blocking=True)
             # the device tensors must outlive the copy although their Python references may not
@@ -53,8 +60,8 @@ class HostStager:
         return slot_id
 
     def collect(self, ticket: int, clone: bool = False):
-        """Wait for the sample's copies; returns (image, label) views of the pinned slot (valid until the slot
-        is submitted again) or private copies when `clone`."""
+        """Wait for the sample's copies; returns (image, label) views of the pinned slot (valid until `keep`
+        further tickets have been collected AND submitted over) or private copies when `clone`."""
         slot = self.slots[ticket]
         slot["event"].synchronize()
         slot["busy"] = False
@@ -67,12 +74,17 @@ class PrefetchingStream:
     """Iterates `indices` of a FetalSynthDataset keeping `depth` samples in flight.
 
     to_host=True : yields the reference contract (image float32 (1,H,W,D) and int64 labels on the CPU, pinned)
-    to_host=False: yields device-resident tensors (float32 image, uint8 labels)."""
+    to_host=False: yields device-resident tensors (float32 image, uint8 labels).
+
+    Lifetime of a yielded host sample: it is a view of a pinned ring slot and stays intact while the consumer
+    holds it and the `keep - 1` samples yielded after it (default keep=2: `prev, cur` patterns are safe;
+    collating B samples needs keep >= B, or `.clone()`)."""
 
     def __init__(self, dataset, indices, base_seed: int = 0, depth: int = 3, to_host: bool = True,
-                 label_dtype=torch.int64):
+                 label_dtype=torch.int64, keep: int = 2):
         self.ds, self.indices, self.base_seed, self.depth, self.to_host = dataset, list(indices), base_seed, depth, to_host
         self.label_dtype = label_dtype
+        self.keep = keep
         self._stager = None
 
     def __len__(self):
@@ -97,7 +109,7 @@ class PrefetchingStream:
         for i in self.indices:
             out, seg, name = self._produce(i)
             if self._stager is None:
-                self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype)
+                self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype, self.keep)
             if len(pending) >= self.depth:
                 t, n = pending.popleft()
                 img, lab = self._stager.collect(t)

@@ -103,7 +103,13 @@ class FetalSynthGen:
 
     # ---- native fused path -------------------------------------------------------------------------
     def _workspace(self, shape, need_rows):
-        """Per (shape, stream) scratch volumes, reused by consecutive samples on that stream."""
+        """Per (shape, stream) scratch volumes, reused by consecutive samples on that stream.
+
+        Eviction (a fifth key appears) and growth of the row workspace drop tensors that kernels already
+        enqueued may still read.  That is safe because every block here is allocated while its key's stream is
+        the current one: the caching allocator hands a freed block only to later requests on the block's OWN
+        allocation stream, which are ordered behind those kernels (tests/test_hip_parity.py::
+        test_workspace_eviction_across_streams)."""
         dev = torch.device(self.device)
         key = (shape, dev.index, K._stream(dev).value)
         ws = self._ws.get(key)
@@ -134,6 +140,21 @@ class FetalSynthGen:
         if seg.dtype != torch.float32:
             seg = seg.float()
         seg = seg.contiguous()
+        # the C side only receives pointers: every operand shape / dtype / device is checked here, because a
+        # mismatched volume would make the fused kernels gather outside a smaller buffer
+        shape = tuple(int(v) for v in shape)
+        if tuple(seg.shape) != shape:
+            raise ValueError(f"segmentation shape {tuple(seg.shape)} differs from the seed volumes' shape {shape}")
+        if not 1 <= len(label_parts) <= 4:
+            raise ValueError(f"{len(label_parts)} seed label volumes: the fused path takes 1..4")
+        for q, part in enumerate(label_parts):
+            off_dev = part.device.type != dev.type or (dev.index is not None and part.device.index != dev.index)
+            if tuple(part.shape) != shape or part.dtype != torch.uint8 or not part.is_contiguous() or off_dev:
+                raise ValueError(
+                    f"seed label volume {q}: expected a contiguous uint8 tensor of shape {shape} on {dev}, got "
+                    f"{part.dtype} {tuple(part.shape)} on {part.device} (contiguous={part.is_contiguous()})")
+        if mus.numel() != sigmas.numel() or not 1 <= mus.numel() <= 256:
+            raise ValueError(f"mus / sigmas tables of {mus.numel()} / {sigmas.numel()} entries (need equal, 1..256)")
         f2 = int(spec.c.field_dims[2]) if spec is not None else 0
         b2 = int(bias_dev.shape[2]) if bias_dev is not None else 0
         ws = self._workspace(shape, 3 * f2 + b2 if spec is not None else 0)

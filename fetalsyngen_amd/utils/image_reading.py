@@ -19,7 +19,38 @@ _DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64
            768: np.uint32}
 
 
+def _qform_affine(raw, pixdim):
+    """NIfTI-1 method 2 (quaternion + offsets; the NIfTI-1 standard's nifti_quatern_to_mat44): qfac = pixdim[0]
+    (-1 flips the third axis), columns scaled by pixdim[1..3]."""
+    b, c, d = struct.unpack("<3f", raw[256:268])
+    off = struct.unpack("<3f", raw[268:280])
+    b, c, d = float(b), float(c), float(d)
+    a2 = 1.0 - (b * b + c * c + d * d)
+    if a2 < 1e-7:  # 180 degree rotation: renormalise (b,c,d), a = 0
+        nrm = 1.0 / np.sqrt(b * b + c * c + d * d)
+        b, c, d, a = b * nrm, c * nrm, d * nrm, 0.0
+    else:
+        a = float(np.sqrt(a2))
+    R = np.array([[a * a + b * b - c * c - d * d, 2 * b * c - 2 * a * d, 2 * b * d + 2 * a * c],
+                  [2 * b * c + 2 * a * d, a * a + c * c - b * b - d * d, 2 * c * d - 2 * a * b],
+                  [2 * b * d - 2 * a * c, 2 * c * d + 2 * a * b, a * a + d * d - c * c - b * b]])
+    zooms = np.array([pixdim[1] if pixdim[1] > 0 else 1.0, pixdim[2] if pixdim[2] > 0 else 1.0,
+                      pixdim[3] if pixdim[3] > 0 else 1.0], dtype=np.float64)
+    qfac = -1.0 if pixdim[0] < 0 else 1.0
+    zooms[2] *= qfac
+    affine = np.eye(4)
+    affine[:3, :3] = R * zooms[None, :]
+    affine[:3, 3] = off
+    return affine
+
+
 def read_nifti(path):
+    """-> (array indexed (x,y,z[,t]), 4x4 voxel->RAS affine, pixdim[1:4]).
+
+    Affine choice: sform when sform_code > 0, else qform when qform_code > 0, else diag(pixdim) -- nibabel's
+    `get_best_affine` order.  (The reference reads through SimpleITK/ITK, which is absent here; when a file
+    carries BOTH forms and they disagree, ITK's choice between them is version dependent: parity unpinned for
+    such files.  The reference's bundled volumes carry consistent, diagonal forms.)"""
     path = str(path)
     with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as fh:
         raw = fh.read()
@@ -30,7 +61,7 @@ def read_nifti(path):
     pixdim = struct.unpack("<8f", raw[76:108])
     vox_offset = int(struct.unpack("<f", raw[108:112])[0])
     slope, inter = struct.unpack("<2f", raw[112:120])
-    sform_code = struct.unpack("<h", raw[254:256])[0]
+    qform_code, sform_code = struct.unpack("<2h", raw[252:256])
     if datatype not in _DTYPES:
         raise ValueError(f"{path}: unsupported NIfTI datatype {datatype}")
     shape = tuple(int(d) for d in dim[1 : 1 + max(dim[0], 3)])
@@ -43,22 +74,52 @@ def read_nifti(path):
     affine = np.eye(4)
     if sform_code > 0:
         affine[:3, :] = np.array(struct.unpack("<12f", raw[280:328])).reshape(3, 4)
+    elif qform_code > 0:
+        affine = _qform_affine(raw, pixdim)
     else:
-        affine[0, 0], affine[1, 1], affine[2, 2] = pixdim[1:4]
+        affine[0, 0], affine[1, 1], affine[2, 2] = [v if v > 0 else 1.0 for v in pixdim[1:4]]
     return np.ascontiguousarray(arr), affine, pixdim[1:4]
 
 
+def io_orientation(affine: np.ndarray) -> np.ndarray:
+    """(3,2) array: for every voxel axis the world axis (0=R,1=A,2=S) it is closest to and the direction (+1/-1).
+
+    Restatement of the published algorithm of nibabel 5.3.2 `orientations.io_orientation` (the routine monai's
+    `Orientation("RAS")` -- reference data/datasets.py:280-284 -- calls; pinned in the reference's
+    environment.yml:110, source not under /root/reference): normalise the columns, take the closest
+    orthogonal matrix (SVD), then walk the voxel axes in order, giving each the not-yet-taken world axis with
+    the largest absolute component.  Works for oblique affines."""
+    rzs = np.asarray(affine, dtype=np.float64)[:3, :3]
+    zooms = np.sqrt(np.sum(rzs * rzs, axis=0))
+    zooms[zooms == 0] = 1
+    rs = rzs / zooms
+    P, S, Qs = np.linalg.svd(rs, full_matrices=False)
+    tol = S.max() * 3 * np.finfo(S.dtype).eps
+    keep = S > tol
+    R = P[:, keep] @ Qs[keep]
+    ornt = np.full((3, 2), np.nan)
+    for in_ax in range(3):
+        col = R[:, in_ax]
+        if not np.allclose(col, 0):
+            out_ax = int(np.argmax(np.abs(col)))
+            ornt[in_ax, 0] = out_ax
+            ornt[in_ax, 1] = -1 if col[out_ax] < 0 else 1
+            R[out_ax, :] = 0  # this world axis is taken
+    if np.isnan(ornt).any():
+        raise ValueError("degenerate affine: a voxel axis has no direction")
+    return ornt
+
+
 def ras_reorient(arr: np.ndarray, affine: np.ndarray):
-    """Permute/flip axes so that the voxel axes run R, A, S (closest-canonical)."""
-    rot = affine[:3, :3]
-    order = [int(np.argmax(np.abs(rot[r, :]))) for r in range(3)]
-    if sorted(order) != [0, 1, 2]:
-        raise ValueError("oblique affine: cannot pick a closest canonical orientation")
-    out = arr.transpose(order)
-    for r in range(3):
-        if rot[r, order[r]] < 0:
-            out = np.flip(out, axis=r)
-    return np.ascontiguousarray(out)
+    """Flip / permute the three leading axes so that they run R, A, S (closest canonical, as monai's
+    `Orientation("RAS")`)."""
+    ornt = io_orientation(affine)
+    out = arr
+    for in_ax in range(3):
+        if ornt[in_ax, 1] < 0:
+            out = np.flip(out, axis=in_ax)
+    order = [int(v) for v in np.argsort(ornt[:, 0])] + list(range(3, arr.ndim))
+    return np.ascontiguousarray(out.transpose(order))
 
 
 class NiftiReader:

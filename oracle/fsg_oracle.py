@@ -82,16 +82,22 @@ def zoom_axis_table(n_src: int, factor: float, n_dst: int):
     return lo.long(), hi.long(), w_lo, w_hi
 
 
-def linear_zoom(x: torch.Tensor, factor) -> torch.Tensor:
+def linear_zoom(x: torch.Tensor, factor, index=None) -> torch.Tensor:
     """Separable linear resize, x then y then z (utils/generation.py:310-397).
     Vectorised over slices; per element the arithmetic is the reference's
-    `w_lo*X[lo] + w_hi*X[hi]` (two fp32 products, one fp32 sum)."""
+    `w_lo*X[lo] + w_hi*X[hi]` (two fp32 products, one fp32 sum).
+    `index` (three int64 index vectors) restricts the OUTPUT to that sub-lattice: the zoom is separable,
+    so the selected elements are computed exactly as in the full result (used at sizes where the full
+    192 MiB x 3 field is not worth materialising on the host)."""
     squeeze = x.dim() == 3
     y = x[..., None] if squeeze else x
     factor = np.asarray(factor, dtype=np.float64)
     new = np.round(np.array(y.shape[:3]) * factor).astype(int)
     for axis in range(3):
         lo, hi, w_lo, w_hi = zoom_axis_table(y.shape[axis], float(factor[axis]), int(new[axis]))
+        if index is not None:
+            sel = torch.as_tensor(index[axis], dtype=torch.long)
+            lo, hi, w_lo, w_hi = lo[sel], hi[sel], w_lo[sel], w_hi[sel]
         bshape = [1, 1, 1, 1]
         bshape[axis] = -1
         y = w_lo.reshape(bshape) * y.index_select(axis, lo) + w_hi.reshape(bshape) * y.index_select(axis, hi)
@@ -170,11 +176,16 @@ def centre_with_shift(shape, size, u_shift64=None) -> torch.Tensor:
     return base + (2 * (ms * u_shift64) - ms)
 
 
-def deformation_coords(shape, size, A: torch.Tensor, c2: torch.Tensor, field):
+def deformation_coords(shape, size, A: torch.Tensor, c2: torch.Tensor, field, index=None):
     """Sampling coordinates of the deformed grid + the six margins
     (affine_nonrigid.py:64-84 grid/centre, :327-366 compose/clamp/margin-subtract).
-    `field` is the full-resolution (H,W,D,3) displacement or None."""
+    `field` is the full-resolution (H,W,D,3) displacement or None.
+    With `index` (three int64 index vectors) only that sub-lattice of the grid is evaluated (`field` then
+    has the sub-lattice's shape); the margins are those of the sub-lattice -- the caller has to make sure
+    they equal the full grid's (e.g. floor(min) == 0 already on the sub-lattice, coordinates being >= 0)."""
     axes = [torch.arange(n, dtype=F32) for n in shape[:3]]
+    if index is not None:
+        axes = [a[torch.as_tensor(ix, dtype=torch.long)] for a, ix in zip(axes, index)]
     centre = torch.tensor((np.array(size) - 1) / 2, dtype=F32)
     g = torch.meshgrid(*axes, indexing="ij")
     p = [g[a] - centre[a] for a in range(3)]

@@ -528,6 +528,34 @@ def g_config1(R, ref):
     save("config1_sta21_128", **res)
 
 
+def g_inputs(ref):
+    """Input side: what the reference's bundled label files hold, read with THIS script's own
+    reader (the reference reads them through SimpleITK + monai Orientation("RAS"), both absent here; the files
+    carry diagonal positive sforms, so RAS orientation is the identity and the voxel array in (x,y,z) order is
+    the expected tensor).  Stored: header fields, label histogram, float64 voxel sum, every 4th voxel."""
+    data = Path(ref) / "data"
+    files = {
+        "dseg": data / "sub-sta21/anat/sub-sta21_rec-irtk_T2w_dseg.nii.gz",
+        "seed": data / "derivatives/seeds/subclasses_3/sub-sta21/anat/sub-sta21_rec-irtk_T2w_dseg_mlabel_2.nii.gz",
+    }
+    res = {}
+    for key, path in files.items():
+        raw = gzip.open(path, "rb").read()
+        arr, pixdim = read_nifti(path)
+        res[f"{key}_relpath"] = np.asarray(str(path.relative_to(ref)))
+        res[f"{key}_dim"] = np.array(struct.unpack("<8h", raw[40:56]))
+        res[f"{key}_datatype"] = np.array(struct.unpack("<h", raw[70:72])[0])
+        res[f"{key}_pixdim"] = np.array(struct.unpack("<8f", raw[76:108]), dtype=np.float32)
+        res[f"{key}_codes"] = np.array(struct.unpack("<2h", raw[252:256]))  # qform_code, sform_code
+        res[f"{key}_quatern"] = np.array(struct.unpack("<6f", raw[256:280]), dtype=np.float32)
+        res[f"{key}_srow"] = np.array(struct.unpack("<12f", raw[280:328]), dtype=np.float32).reshape(3, 4)
+        res[f"{key}_sum"] = np.float64(arr.astype(np.float64).sum())
+        res[f"{key}_hist"] = np.bincount(arr.astype(np.int64).reshape(-1), minlength=64)
+        res[f"{key}_sub4"] = arr[::4, ::4, ::4].astype(np.uint8)
+        res[f"{key}_centre_x"] = arr[arr.shape[0] // 2].astype(np.uint8)
+    save("inputs_sta21", **res)
+
+
 def _rigid_transforms(rng, n, max_rot=0.5, max_t=3.0):
     """n random 3x4 [R|t] (rotation about a random axis, translation), float32."""
     out = np.zeros((n, 3, 4), dtype=np.float32)
@@ -885,6 +913,9 @@ def main():
     if not args.only or args.only == "config1":
         print("config1")
         g_config1(R, args.ref)
+    if not args.only or args.only == "inputs":
+        print("inputs")
+        g_inputs(args.ref)
 
 
 if __name__ == "__main__":

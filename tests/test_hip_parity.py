@@ -539,8 +539,6 @@ def test_rowwise_kernels_equal_per_voxel_kernels(K, golden):
         for flags in (0, 1, 2):
             mm, out, seg, plain = res[(flags, flip)]
             assert np.array_equal(mm, base[0]) and np.array_equal(seg, base[2]) and np.array_equal(plain, base[3])
-            if flags & 2 or flags == 1:
-                pass
             np.testing.assert_allclose(out, base[1], rtol=RTOL, atol=ATOL)
         assert np.array_equal(res[(2, flip)][1], base[1])  # rows + precise math == per-voxel + precise math
     # zoom family
@@ -948,10 +946,33 @@ def test_config4_384_hot_path_properties(K):
     frac = float((lab > 0).float().mean())
     assert 0.5 * float((segd > 0).float().mean()) < frac < 1.6 * float((segd > 0).float().mean())
     assert params["deform_params"]["non_rigid"]["size_F_small"][0] in range(11, 25)
-    # the oracle on a coarse sub-lattice of the SAME deformation: labels at every 16th voxel must match exactly
-    spec_params = params["deform_params"]
-    A = O.affine_matrix(spec_params["affine"]["rotations"], spec_params["affine"]["shears"], spec_params["affine"]["scalings"])
-    assert A.shape == (3, 3)
+    # the oracle on a coarse sub-lattice of the SAME deformation: labels at every 16th voxel must match exactly.
+    # The host plan is replayed (same seeds -> same draws, in the reference's order) to recover A, c2 and the
+    # coarse field; the oracle then evaluates zoom + coordinates only at the lattice points.
+    from fetalsyngen_amd import rng as _rng
+
+    np.random.seed(5)
+    torch.manual_seed(5)
+    with _rng.use("device"):
+        gen.intensity_generator.draw_subclusters({})
+        gen.intensity_generator.plan_intensities(shape, {})
+        dplan = gen.spatial_deform.plan(shape, random_shift=True, genparams={})
+    dp = params["deform_params"]
+    assert dplan.active and np.array_equal(dplan.params["affine"]["rotations"], dp["affine"]["rotations"])
+    assert dplan.params["non_rigid"]["size_F_small"] == dp["non_rigid"]["size_F_small"] and dplan.flip == dp["flip"]
+    A64 = O.affine_matrix(dp["affine"]["rotations"], dp["affine"]["shears"], dp["affine"]["scalings"])
+    assert np.array_equal(A64.astype(np.float32), dplan.A.numpy())
+    # every 16th voxel plus the last index of each axis (the corners are where the clamps bite)
+    index = [np.unique(np.r_[np.arange(0, n, 16), n - 1]) for n in shape]
+    fs = dplan.field_small
+    f_sub = O.linear_zoom(fs, np.array(shape) / np.array(fs.shape[:3]), index=index)
+    ii, jj, kk, margins = O.deformation_coords(shape, gen.spatial_deform.size, dplan.A, dplan.c2, f_sub, index=index)
+    assert tuple(margins[:3]) == (0, 0, 0), "sub-lattice must already contain a coordinate < 1 per axis (floor(min) = 0)"
+    seg_t = t(seg)
+    want = O.sample_nearest(torch.flip(seg_t, [0]) if dplan.flip else seg_t, ii, jj, kk)
+    got = lab.cpu()[np.ix_(*index)]
+    assert got.shape == want.shape and torch.equal(got.float(), want.float()), "labels on the 16-voxel lattice, exact"
+    assert int((want > 0).sum()) > 500  # the lattice does see the labelled region
     lazy = make_generator(shape, DEV, rng="device", prob=0.0)
     np.random.seed(5)
     torch.manual_seed(5)
@@ -963,6 +984,64 @@ def test_config4_384_hot_path_properties(K):
     for l in torch.nonzero(cnt > 200000).flatten().tolist():
         if float(mus[l]) > 4 * float(sig[l]):
             assert abs(float(mean[l]) - float(mus[l])) < 0.05 and abs(float(var[l]) ** 0.5 - float(sig[l])) < 0.05
+
+
+def test_workspace_eviction_across_streams(K):
+    """More (shape, stream) keys than `FetalSynthGen._ws` keeps (4): samples interleaved over 6 streams evict
+    each other's scratch volumes while kernels are still in flight; every result must equal the same sample
+    made alone on the default stream."""
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (96, 96, 96)
+    seg, seeds = make_seed_volumes(shape, 1)
+    bank, segd = SeedBank(seeds, DEV), dev(seg)
+    gen = make_generator(shape, DEV, rng="device", prob=1.0, nonlin_scale=(0.05, 0.12), bf_scale=(0.02, 0.08))
+
+    def produce(i):
+        sharding.seed_for_sample(77, i)
+        out, lab, _, _ = gen._pipeline(None, segd, bank, {}, scale01=True)
+        return out, lab
+
+    want = [tuple(x.clone() for x in produce(i)) for i in range(24)]
+    torch.cuda.synchronize()
+    gen._ws.clear()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(6)]
+    got, keys_seen = [], set()
+    for i in range(24):
+        with torch.cuda.stream(streams[i % 6]):
+            got.append(produce(i))
+        keys_seen.update(gen._ws)
+        assert len(gen._ws) <= 4
+    assert len(keys_seen) == 6  # six keys went through a cache of four: evictions happened mid-flight
+    torch.cuda.synchronize()
+    for (wo, wl), (go, gl) in zip(want, got):
+        assert torch.equal(wo, go) and torch.equal(wl, gl)
+
+
+def test_run_native_rejects_mismatched_operands(K):
+    """The fused path only hands pointers to the C side: a segmentation (or seed volume) of another shape must be
+    refused on the host, not gathered out of bounds on the device."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (32, 32, 32)
+    seg, seeds = make_seed_volumes(shape, 0)
+    bank = SeedBank(seeds, DEV)
+    gen = make_generator(shape, DEV, rng="device", prob=1.0, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+    with pytest.raises(ValueError, match="segmentation shape"):
+        gen._pipeline(None, dev(seg[:24]), bank, {}, scale01=True)
+    small = make_seed_volumes((24, 32, 32), 0)[1]
+    mixed = {n: {m: (small[n][m] if m == 2 else v) for m, v in d.items()} for n, d in seeds.items()}
+
+    class Bank(SeedBank):
+        pass
+
+    with pytest.raises(ValueError, match="seed label volume"):
+        gen._pipeline(None, dev(seg), Bank(mixed, DEV), {}, scale01=True)
+    out, lab, _, _ = gen._pipeline(None, dev(seg), bank, {}, scale01=True)  # and the matching call still works
+    assert tuple(out.shape) == shape and tuple(lab.shape) == shape
 
 
 def test_config5_streaming_epoch_through_a_dataloader(K, tmp_path):
@@ -1012,12 +1091,42 @@ def test_host_stager_matches_synchronous_copy(K, tmp_path):
     got = [(d["image"].clone(), d["label"].clone()) for d in PrefetchingStream(ds, range(7), base_seed=5, depth=2)]
     assert len(got) == 7
     for (wi, wl), (gi, gl) in zip(want, got):
-        assert gi.is_pinned() or True
+        assert not gi.is_cuda and not gl.is_cuda
         assert torch.equal(gi, wi) and gl.dtype == torch.int64 and torch.equal(gl, wl.long())
-    st = HostStager(shape, DEV, depth=1)
+    st = HostStager(shape, DEV, depth=1, keep=1)
     x, y = torch.rand(shape, device=DEV), torch.ones(shape, device=DEV)
     tk = st.submit(x, y)
+    tk2 = st.submit(x, y)
     with pytest.raises(RuntimeError, match="overrun"):
         st.submit(x, y)
     img, lab = st.collect(tk)
     assert torch.equal(img.view(shape), x.cpu()) and int(lab.sum()) == int(np.prod(shape))
+    st.collect(tk2)
+
+
+def test_host_stager_keeps_yielded_samples_alive_and_labels_intact(K, tmp_path):
+    """Several 128^3 samples in flight (48 MiB of D2H each, so copies lag the generator), items consumed WITHOUT
+    cloning in a `prev, cur` pattern: a yielded sample must stay intact while the next one is being used, and the
+    label conversion must not read a recycled device block (the source of the int64 conversion is freed by the
+    producer right after submit)."""
+    from tests.util_bids import write_tree
+    from fetalsyngen_amd.data.datasets import FetalSynthDataset
+    from fetalsyngen_amd.data.staging import PrefetchingStream
+
+    shape = (128, 128, 128)
+    bids, seed_dir = write_tree(tmp_path, shape, ["sub-a"])
+    gen = make_generator(shape, DEV, rng="device", prob=1.0)
+    ds = FetalSynthDataset(str(bids), gen, str(seed_dir), None)
+    ds.sample(0)
+    n = 10
+    want = [(d["image"].cpu().clone(), d["label"].cpu().clone().long())
+            for d in PrefetchingStream(ds, range(n), base_seed=9, to_host=False)]
+    for label_dtype in (torch.int64, torch.uint8):
+        prev, seen = None, 0
+        for k, cur in enumerate(PrefetchingStream(ds, range(n), base_seed=9, depth=3, label_dtype=label_dtype)):
+            assert cur["image"].is_pinned() and cur["label"].dtype == label_dtype
+            if prev is not None:  # the previous item is still what it was when it was yielded
+                assert torch.equal(prev["image"], want[k - 1][0]) and torch.equal(prev["label"].long(), want[k - 1][1])
+            assert torch.equal(cur["image"], want[k][0]) and torch.equal(cur["label"].long(), want[k][1])
+            prev, seen = cur, seen + 1
+        assert seen == n

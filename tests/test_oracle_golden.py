@@ -194,3 +194,28 @@ def test_config1_sta21_128(golden):
     st = np.array([sc.min(), sc.max(), sc.mean(dtype=np.float64), sc.std(dtype=np.float64)])
     np.testing.assert_allclose(st, g["stats"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(sc[64], g["slice_x"].astype(np.float32), atol=1e-3)
+
+
+def test_sublattice_option_equals_the_full_evaluation():
+    """`index=` of linear_zoom / deformation_coords (used by the 384^3 GPU test) selects exactly the values of
+    the full evaluation."""
+    import numpy as np
+    import torch
+
+    from oracle import fsg_oracle as O
+
+    torch.manual_seed(3)
+    shape = (40, 36, 28)
+    fs = 2.5 * torch.randn(5, 4, 3, 3)
+    index = [np.unique(np.r_[np.arange(0, n, 7), n - 1]) for n in shape]
+    factor = np.array(shape) / np.array(fs.shape[:3])
+    full = O.linear_zoom(fs, factor)
+    sub = O.linear_zoom(fs, factor, index=index)
+    assert torch.equal(sub, full[np.ix_(*index)])
+    A = torch.tensor(O.affine_matrix([0.2, -0.1, 0.15], [0.01, -0.02, 0.0], [1.05, 0.95, 1.0]), dtype=torch.float32)
+    c2 = O.centre_with_shift(shape, shape)
+    fi, fj, fk, fm = O.deformation_coords(shape, shape, A, c2, full)
+    si, sj, sk, sm = O.deformation_coords(shape, shape, A, c2, sub, index=index)
+    assert tuple(fm[:3]) == (0, 0, 0) and tuple(sm[:3]) == (0, 0, 0)
+    ix = np.ix_(*index)
+    assert torch.equal(si, fi[ix]) and torch.equal(sj, fj[ix]) and torch.equal(sk, fk[ix])
