@@ -6,18 +6,30 @@
 One step = one full pass of the path (GMM draw -> deformation min/max -> fused warp(+gamma+bias,
 labels) -> 3-pass Gaussian blur -> resample+noise -> zoom-back+[0,1] normalise) over one synthetic
 256^3 label volume that is already resident in HBM (uint8 seed labels + fp32 segmentation), every
-stage gate on, device-Philox RNG, outputs left in HBM.  N > 1: one process per GPU (launched by
-torch.distributed.run), every rank processes its own volumes (independent work, no collective in the
-data path; gloo is used for the barrier and the max-over-ranks time only).
+stage gate on, device-Philox RNG, outputs left in HBM.
 
-Prints ONE JSON line (rank 0).
+N > 1: one process per GPU.  Either the caller creates the ranks (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when
+WORLD_SIZE is NOT set -- this script starts N child ranks itself before anything touches a GPU, waits for
+them and relays rank 0's line (the parent never initialises HIP).  Every rank processes its own volumes
+(independent work, no collective in the data path; a gloo group carries the barrier, the max-over-ranks
+time and the per-rank reports only).
+
+Prints ONE JSON line (rank 0).  Beside the headline (`value`, BASELINE configs[1]) the line carries
+`roofline` (blur kernel, live HIP events), `roofline_step`, `config3` (32 x 256^3 volumes dealt i % N,
+strong scaling), `config5` (streaming epoch, CPU-tensor contract and device-resident), `ranks`, and at
+N = 1 `blur_microbench`, `config4_sr`, `cpu_baseline`.
+
+`--dry-plan`: no GPU work at all -- every rank only draws the host plans of its samples (what the Python
+side does per sample); used by the CPU test of the N-rank launcher and as a host-cost probe.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,12 +37,103 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable copy
+# the real reference timed in the build container: the anchor the CPU port is read against
+REFERENCE_ANCHOR = {"value": 0.156, "unit": "volumes/s", "threads": 8, "s_per_volume": 6.42,
+                    "what": "real reference (imported, CPU, torch 2.10, all gates on, sub-sta21 256^3) in the build "
+                            "container, BASELINE.md section 2; the port below vectorises the reference's Python loops "
+                            "and is therefore FASTER than the reference"}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--rng", default="device", choices=["device", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-sr", action="store_true", help="skip the 384^3 SimulateMotion side line")
+    ap.add_argument("--no-config3", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--batch-volumes", type=int, default=32, help="config3: volumes in the batch dealt i %% N")
+    ap.add_argument("--stream-volumes", type=int, default=2000, help="config5: volumes streamed per rank and mode")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the samples are spread over (round robin)")
+    ap.add_argument("--dry-plan", action="store_true", help="host plans only, no GPU (launcher test / host-cost probe)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------
+# N-rank launcher (parent process: never touches a GPU)
+# ----------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start `--gpus` child ranks of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set per child), wait, check
+    that N distinct devices reported, relay rank 0's JSON line.  Exit code != 0 if any child failed."""
+    import tempfile
+
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0_file:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), FSG_BENCH_CHILD="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                          stdout=out0_file if r == 0 else subprocess.DEVNULL, stderr=None))
+        # a rank that dies would leave the others waiting in a barrier: stop them (exact PIDs) as soon as one fails
+        codes = [None] * n
+        while any(c is None for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = pr.poll()
+            if any(c not in (None, 0) for c in codes):
+                for r, pr in enumerate(procs):
+                    if codes[r] is None:
+                        pr.terminate()
+                for r, pr in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = pr.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            pr.kill()
+                            codes[r] = pr.wait()
+                break
+            time.sleep(0.1)
+        out0_file.seek(0)
+        out0 = out0_file.read()
+    if any(codes):
+        sys.stderr.write(f"bench.py launcher: rank exit codes {codes}\n")
+        sys.stdout.write(out0 or "")
+        return 1
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        sys.stderr.write("bench.py launcher: rank 0 printed no JSON line\n")
+        return 1
+    res = json.loads(line)
+    ranks = res.get("ranks", [])
+    shared = bool(os.environ.get("FSG_BENCH_SHARE_GPU0")) or args.dry_plan
+    devices = {(r.get("device"), r.get("uuid")) for r in ranks}
+    if res.get("n_gpus") != n or sorted(r.get("rank") for r in ranks) != list(range(n)) or (
+            not shared and len(devices) != n):
+        sys.stderr.write(f"bench.py launcher: expected {n} ranks on {n} distinct devices, got n_gpus={res.get('n_gpus')} "
+                         f"ranks={ranks}\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------
 def build_generator(shape, device, rng_mode):
     from fetalsyngen_amd.generator.augmentation.synthseg import RandBiasField, RandGamma, RandNoise, RandResample
     from fetalsyngen_amd.generator.deformation.affine_nonrigid import SpatialDeformation
@@ -58,16 +161,33 @@ def _drop_events(events):
     events.clear()
 
 
-def blur_traffic_per_sample(passes, size):
-    """HBM-side bytes of one sample's blur (x pass + fused y,z pass) from the committed PMC summary (profiles/r*_blur_pmc.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate rocprofv3 --pmc passes of the same kernels, gfx950 x2 fetch
-    correction applied), averaged over the radius mix this run actually launched."""
+def _blur_launch_plan(sec):
+    """[(kernel prefix of the PMC table, radius)] for one sample's blur section `[(axis, radius), ...]`: x pass, then
+    the fused y+z launch when both are active with the same radius (<= 8), else one launch per axis."""
+    byaxis = dict(sec)
+    out = []
+    if 0 in byaxis:
+        out.append(("blur_strided_v4<", byaxis[0]))
+    if 1 in byaxis and 2 in byaxis and byaxis[1] == byaxis[2] and byaxis[1] <= 8:
+        out.append(("blur_yz_fused_kernel<", byaxis[1]))
+    else:
+        for axis in (1, 2):
+            if axis in byaxis:
+                out.append(("blur_contig_lds<" if axis == 2 else "blur_strided_v4<", byaxis[axis]))
+    return out
+
+
+def blur_traffic(sections, size):
+    """HBM-side bytes of the timed blur launches from the committed PMC summary (profiles/r*_blur_pmc.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc passes of the same kernels, gfx950 x2 fetch correction applied),
+    averaged over the radius mix this run actually launched.  -> (bytes per launch, launches) or (None, launches)."""
+    launches = [l for sec in sections for l in _blur_launch_plan(sec)]
     files = sorted((REPO / "profiles").glob("r*_blur_pmc.json"))
-    if not files or not passes:
-        return None
+    if not files or not launches:
+        return None, len(launches)
     table = json.loads(files[-1].read_text())["sizes"].get(str(size))
     if not table:
-        return None
+        return None, len(launches)
 
     def lookup(prefix, R):
         pts = {}
@@ -85,38 +205,22 @@ def blur_traffic_per_sample(passes, size):
             if lo_ <= R <= hi_:
                 return pts[lo_] + (pts[hi_] - pts[lo_]) * (R - lo_) / (hi_ - lo_)
 
-    # per blur section: x pass, then the fused y+z launch when both are active with the same radius (<= 8), else two passes
-    tot, nsec = 0.0, 0
-    i = 0
-    while i < len(passes):
-        sec = []
-        while i < len(passes) and (not sec or passes[i][0] > sec[-1][0]):
-            sec.append(passes[i])
-            i += 1
-        byaxis = dict(sec)
-        if 0 in byaxis:
-            t = lookup("blur_strided_v4<", byaxis[0])
-            if t is None:
-                return None
-            tot += t
-        if 1 in byaxis and 2 in byaxis and byaxis[1] == byaxis[2] and byaxis[1] <= 8:
-            t = lookup("blur_yz_fused_kernel<", byaxis[1])
-            if t is None:
-                return None
-            tot += t
-        else:
-            for axis in (1, 2):
-                if axis in byaxis:
-                    t = lookup("blur_contig_lds<" if axis == 2 else "blur_strided_v4<", byaxis[axis])
-                    if t is None:
-                        return None
-                    tot += t
-        nsec += 1
-    return round(tot / max(nsec, 1))
+    tot = 0.0
+    for prefix, R in launches:
+        t = lookup(prefix, R)
+        if t is None:
+            return None, len(launches)
+        tot += t
+    return tot / len(launches), len(launches)
 
 
 def blur_microbench(shape, device, sigma=1.3, reps=20):
-    """Back-to-back launches of each axis pass between HIP events; algorithmic bytes = 8 B/voxel/pass."""
+    """Back-to-back launches of each blur kernel between HIP events.  GBps = bytes the launch must move (read the volume
+    once + write it once = 8 B/voxel, also for the fused y+z launch, whose intermediate never leaves LDS) / time; the
+    fused launch additionally reports the two-pass equivalent (16 B/voxel of per-pass algorithmic bytes)."""
+    import numpy as np
+    import torch
+
     from fetalsyngen_amd import kernels as K
     from fetalsyngen_amd import tables as T
 
@@ -127,29 +231,26 @@ def blur_microbench(shape, device, sigma=1.3, reps=20):
     bufs = [torch.rand(shape, device=device) * 255 for _ in range(6)]
     for label, pool in (("l3_warm", bufs[:1]), ("l3_cold", bufs)):
         res = {}
-        for axis in range(3):
+
+        def timed(fn):
             for w in range(3):
-                K.blur_axis(pool[w % len(pool)], axis, taps)
+                fn(pool[w % len(pool)])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
             for r in range(reps):
-                K.blur_axis(pool[r % len(pool)], axis, taps)
+                fn(pool[r % len(pool)])
             e1.record()
             torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
+            return e0.elapsed_time(e1) * 1e3 / reps
+
+        for axis in range(3):
+            us = timed(lambda x, a=axis: K.blur_axis(x, a, taps))
             res[f"axis{axis}"] = {"us": round(us, 2), "GBps": round(8.0 * nvox / us / 1e3, 1)}
-        # the y and z passes as one launch: two passes' algorithmic bytes (16 B/voxel)
         if K.blur_yz(pool[0], taps, taps) is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for r in range(reps):
-                K.blur_yz(pool[r % len(pool)], taps, taps)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            res["fused_yz"] = {"us": round(us, 2), "GBps": round(16.0 * nvox / us / 1e3, 1)}
+            us = timed(lambda x: K.blur_yz(x, taps, taps))
+            res["fused_yz"] = {"us": round(us, 2), "GBps": round(8.0 * nvox / us / 1e3, 1),
+                               "two_pass_equivalent_GBps": round(16.0 * nvox / us / 1e3, 1)}
         out[label] = res
     return out
 
@@ -157,6 +258,9 @@ def blur_microbench(shape, device, sigma=1.3, reps=20):
 def config4_sr(device, size=384, reps=3):
     """BASELINE configs[3] side line (not the metric): the SR-artifact slice-stack simulation (SimulateMotion = Scanner.scan +
     PSFReconstructor.recon_psf, default YAML ranges, device RNG) on one 384^3 / 0.5 mm volume, wall ms per volume."""
+    import numpy as np
+    import torch
+
     from fetalsyngen_amd.generator.defaults import default_artifacts
     from fetalsyngen_amd.phantom import make_segmentation
 
@@ -182,6 +286,9 @@ def config4_sr(device, size=384, reps=3):
 def cpu_baseline(shape, threads):
     """The CPU restatement of the reference path (oracle/, validated against the real reference by the
     golden vectors) timed on this host: one warm-up + four timed full-size samples."""
+    import numpy as np
+    import torch
+
     from fetalsyngen_amd.phantom import make_seed_volumes
     from oracle import fsg_oracle as O
 
@@ -199,38 +306,98 @@ def cpu_baseline(shape, threads):
     timed = times[1:]
     return {"value": round(len(timed) / sum(timed), 4), "unit": "volumes/s", "cores": threads, "kind": "port",
             "sample": f"1 warm-up + {len(timed)} timed {shape[0]}^3 volumes, all gates on, torch CPU ops "
-                      f"({sum(timed):.2f} s, {min(timed):.2f}-{max(timed):.2f} s per volume)"}
+                      f"({sum(timed):.2f} s, {min(timed):.2f}-{max(timed):.2f} s per volume)",
+            "reference_anchor": REFERENCE_ANCHOR}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--rng", default="device", choices=["device", "reference"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-microbench", action="store_true")
-    ap.add_argument("--no-sr", action="store_true", help="skip the 384^3 SimulateMotion side line")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the samples are spread over (round robin)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------------
+class Ranks:
+    """The little cross-rank traffic a benchmark of independent replicas needs (gloo): barrier, max of a time, gather of
+    small Python objects."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    import torch.distributed as dist
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        if world > 1:
+            import torch.distributed as dist
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        # one process per GPU: keep each rank's host-side plans (small numpy / torch CPU ops) on its share of the cores
-        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def run_dry_plan(args, R: Ranks):
+    """Host plans only: what the Python side does per sample before the one native call (no GPU, no HIP library)."""
+    from fetalsyngen_amd import sharding
+
+    shape = (args.size,) * 3
+    gen = build_generator(shape, "cuda:0", args.rng if args.rng == "device" else "device")
+    for i in range(args.warmup):
+        sharding.seed_for_sample(1234, R.rank + R.world * i)
+        gen.plan_only(shape)
+    R.barrier()
+    t0 = time.perf_counter()
+    digest = 0.0
+    for i in range(args.steps):
+        sharding.seed_for_sample(1234, R.rank + R.world * (args.warmup + i))
+        plans = gen.plan_only(shape)
+        digest += float(plans[1].mus.sum())
+    R.barrier()
+    dt_rank = time.perf_counter() - t0
+    dt = R.max(dt_rank)
+    reports = R.gather({"rank": R.rank, "device": "none (dry plan)", "uuid": None, "pid": os.getpid(),
+                        "plans_per_s": round(args.steps / dt_rank, 1), "digest": round(digest, 3)})
+    if R.rank == 0:
+        print(json.dumps({
+            "metric": "host plans/sec (dry plan: all per-sample host draws, no GPU work)", "value": round(R.world * args.steps / dt, 1),
+            "unit": "plans/s", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64/f32 host", "data": "synthetic", "dry_plan": True,
+            "config": {"workload": f"host plans of BASELINE configs[1] ({args.size}^3), no device work"},
+            "ranks_seen": sorted(r["rank"] for r in reports), "ranks": reports}), flush=True)
+
+
+def run(args, rank, world, local):
+    import numpy as np
+    import torch
+
+    R = Ranks(rank, world)
+    # one process per GPU: keep each rank's host-side plans (small numpy / torch CPU ops) on its share of the cores
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
+    if args.dry_plan:
+        run_dry_plan(args, R)
+        R.close()
+        return 0
+
+    import ctypes
 
     from fetalsyngen_amd import _lib
     from fetalsyngen_amd import sharding
-    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.data.datasets import MemorySynthDataset, SeedBank
+    from fetalsyngen_amd.data.staging import PrefetchingStream
     from fetalsyngen_amd.phantom import make_seed_volumes
 
     _lib.load()  # fail loudly if the HIP library is missing
@@ -238,75 +405,92 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
     if os.environ.get("FSG_BENCH_SHARE_GPU0"):  # rehearsal of the N>1 path on a 1-GPU box: every rank on cuda:0
         local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     device = f"cuda:{local}"
     torch.cuda.set_device(device)
+    props = torch.cuda.get_device_properties(local)
     shape = (args.size,) * 3
     nvox = int(np.prod(shape))
 
-    # inputs resident in HBM before the timed region: 4 distinct label volumes per rank
-    banks, segs = [], []
+    # inputs resident in HBM before any timed region: 4 distinct label volumes (the same four on every rank, so that
+    # the batch of config3 does not depend on N); further "subjects" are cheap on-device transforms of these
+    base_banks, base_segs = [], []
     for v in range(4):
-        seg, seeds = make_seed_volumes(shape, variant=rank * 4 + v)
-        banks.append(SeedBank(seeds, device))
-        segs.append(torch.from_numpy(seg).to(device))
+        seg, seeds = make_seed_volumes(shape, variant=v)
+        base_banks.append(SeedBank(seeds, device))
+        base_segs.append(torch.from_numpy(seg).to(device))
+
+    def subject(k):
+        """Label volumes of synthetic subject k: base variant k % 4, rolled 8*(k//4) voxels along y, mirrored in z for odd k//4."""
+        b, r = k % 4, k // 4
+        if r == 0:
+            return base_segs[b], base_banks[b]
+        fn = (lambda x: torch.roll(x, 8 * r, 1).flip(2).contiguous()) if r % 2 else (lambda x: torch.roll(x, 8 * r, 1).contiguous())
+        return fn(base_segs[b]), base_banks[b].transformed(fn)
+
     gen = build_generator(shape, device, args.rng)
     gen.prewarm()  # static per-axis tables of this configuration -> device (outside the timed region)
 
-    blur_ms = []
+    result_extra = {}
+    if rank == 0 and not args.no_microbench:
+        result_extra["blur_microbench"] = blur_microbench(shape, device)
 
     streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else [None]
+    mus_seen = []
 
-    def step(i, timed):
+    def step(i):
         sharding.seed_for_sample(1234, rank + world * i)
         k = i % 4
         st = streams[i % len(streams)]
         if st is None:
-            out, seg_d, _img, _p = gen._pipeline(None, segs[k], banks[k], {}, scale01=True)
+            out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True)
         else:
             with torch.cuda.stream(st):
-                out, seg_d, _img, _p = gen._pipeline(None, segs[k], banks[k], {}, scale01=True)
-        return out, seg_d
+                out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True)
+        return out, seg_d, p
 
-    # per-step blur timing: HIP events recorded on the launch stream around the three axis passes of every
-    # sample, inside fsg_sample_run (FetalSynthGen.blur_events)
+    # ---- headline: BASELINE configs[1], W untimed + K timed steps, barrier + synchronize on both sides ----------
+    # per-step blur timing: HIP events recorded on the launch stream around the blur launches of every sample,
+    # inside fsg_sample_run (FetalSynthGen.blur_events)
     gen.blur_events = []
-
     for i in range(args.warmup):
-        step(i, False)
+        step(i)
     torch.cuda.synchronize()
     _drop_events(gen.blur_events)
-    if world > 1:
-        dist.barrier()
+    R.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, True)
+        _o, _s, p = step(args.warmup + i)
+        mus_seen.append(p["resample_params"]["spacing"])
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    R.barrier()
+    dt_rank = time.perf_counter() - t0
+    dt = R.max(dt_rank)
+
     lib = _lib.load()
-    sections, blur_total_ms, passes = 0, 0.0, []
+    blur_total_ms, sections = 0.0, []
     ms = ctypes.c_float()
     for e0, e1, pl in gen.blur_events:
         _lib.check(lib.fsg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "fsg_event_elapsed_ms")
         blur_total_ms += ms.value
-        sections += 1
-        passes.extend(pl)
+        sections.append(pl)
     _drop_events(gen.blur_events)
     gen.blur_events = None
-    # one blur = three axis passes (8 B/voxel/pass, 24 B/voxel for the blur) issued as two launches: the x pass
-    # and the fused y+z pass (the intermediate stays in LDS)
-    npass = len(passes)
-    blur_us = blur_total_ms * 1e3 / max(sections, 1)           # per sample
-    alg_bytes = 8.0 * nvox * npass / max(sections, 1)          # per sample
-    achieved = alg_bytes / blur_us / 1e3 if sections else 0.0  # GB/s
+    traffic_launch, nlaunch = blur_traffic(sections, args.size)
+    npass = sum(len(s) for s in sections)
+    us_launch = blur_total_ms * 1e3 / max(nlaunch, 1)
+    # bytes ONE blur launch must move: the volume read once and written once (8 B/voxel).  The fused y+z launch does two
+    # axis passes for those bytes (its intermediate stays in LDS): the pass-equivalent rate is reported separately.
+    bytes_launch = 8.0 * nvox
+    achieved = bytes_launch / us_launch / 1e3 if nlaunch else 0.0
+    # whole step: SURVEY 8(d) per-kernel algorithmic bytes with the fusions as built (gamma/bias in the warp epilogue: 0;
+    # K9+K10 one evaluation): K1 5 + warp 8 (image) + 8 (f32 labels) + blur 24 + K7 (4 + 4mu) + K9 (4mu + 4) B/voxel
+    size_v = float(args.size)
+    mu = float(np.mean([(int(size_v * 0.5 / s[0]) / size_v) ** 3 for s in mus_seen if s])) if mus_seen else 1.0
+    step_bytes = (53.0 + 8.0 * mu) * nvox
 
-    traffic_sample = blur_traffic_per_sample(passes, args.size)  # HBM bytes of the two launches (committed PMC table)
     result = {
         "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
         "value": round(world * args.steps / dt, 3),
@@ -325,29 +509,127 @@ def main():
                    "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
                    "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams},
         "roofline": {"bound": "hbm",
-                     "kernel": "separable 3-pass blur = x pass (fsg_blur_axis_taps_host_f32) + fused y,z pass "
-                               "(fsg_blur_yz_taps_host_f32), HIP events around both launches of every timed sample",
+                     "kernel": "separable 3-pass blur = x pass (blur_strided_v4) + fused y,z pass (blur_yz_fused_kernel), "
+                               "HIP events on the launch stream around the blur launches of every timed sample (rank 0)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": (None if traffic_sample is None else int(traffic_sample / 2)),  # per launch, like achieved
-                     "us_per_launch": round(blur_us / 2, 2), "launches_timed": 2 * sections,
-                     "algorithmic_bytes_per_launch": int(alg_bytes / 2),
-                     "per_sample": {"us": round(blur_us, 2), "axis_passes": round(npass / max(sections, 1), 2), "launches": 2,
-                                    "algorithmic_bytes": int(alg_bytes), "traffic": traffic_sample}},
+                     "traffic": (None if traffic_launch is None else int(traffic_launch)),
+                     "us_per_launch": round(us_launch, 2), "launches_timed": nlaunch,
+                     "algorithmic_bytes_per_launch": int(bytes_launch),
+                     "accounting": "8 B/voxel per launch (volume read once + written once); the fused y+z launch covers two "
+                                   "axis passes with those bytes",
+                     "effective_pass_GBps": round(8.0 * nvox * npass / max(blur_total_ms * 1e3, 1e-9) / 1e3, 1),
+                     "axis_passes_per_sample": round(npass / max(len(sections), 1), 2),
+                     "launches_per_sample": round(nlaunch / max(len(sections), 1), 2)},
+        "roofline_step": {"bound": "hbm", "bytes_per_voxel": "53 + 8*mu (K1 5, warp 16 with f32 labels, blur 24, K7 4+4mu, K9/K10 4+4mu)",
+                          "mu_mean": round(mu, 4), "algorithmic_bytes_per_step": int(step_bytes),
+                          "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    result.update(result_extra)
+
+    # ---- config3: a batch of B volumes dealt i % N (strong scaling), per-sample keys independent of N -------------
+    c3 = None
+    if not args.no_config3:
+        B = args.batch_volumes
+        mine = list(sharding.shard(B, rank, world))
+        subj = {i: subject(i) for i in mine}
+        walls, outs = [], {}
+        for rep in range(4):  # first repetition is a warm-up of the allocator for this many live outputs
+            outs.clear()
+            torch.cuda.synchronize()
+            R.barrier()
+            t0 = time.perf_counter()
+            for i in mine:
+                sharding.seed_for_sample(4321, i)
+                o, s_, _im, _p = gen._pipeline(None, subj[i][0], subj[i][1], {}, scale01=True)
+                outs[i] = (o, s_)
+            torch.cuda.synchronize()
+            R.barrier()
+            walls.append(R.max(time.perf_counter() - t0))
+        sums = {i: [float(o.double().sum()), float(s_.double().sum())] for i, (o, s_) in outs.items()}
+        allsums = {}
+        for d in R.gather(sums):
+            allsums.update(d)
+        outs.clear()
+        subj.clear()
+        wall = float(np.median(walls[1:]))
+        c3 = {"workload": f"BASELINE configs[2]: batch of {B} distinct {args.size}^3 label volumes, sample i on rank i % {world}, "
+                          "keys (base_seed, i) independent of N, outputs kept in HBM",
+              "scaling": "strong", "volumes": B, "wall_ms": round(wall * 1e3, 3), "wall_ms_runs": [round(w * 1e3, 3) for w in walls[1:]],
+              "volumes_per_s": round(B / wall, 1),
+              "checksum": round(sum(v[0] for v in allsums.values()), 6), "label_checksum": round(sum(v[1] for v in allsums.values()), 1),
+              "checksum_note": "sum over the batch of each output's float64 voxel sum: equal for every N when the batch is independent of the sharding"}
+
+    # ---- config5: streaming epoch into a consumer, (a) reference contract on the CPU, (b) device-resident ----------
+    c5 = None
+    if not args.no_config5:
+        ds = MemorySynthDataset(gen, base_segs, base_banks)
+        n_stream = args.stream_volumes
+        idx = [rank + world * j for j in range(n_stream)]
+        c5 = {"workload": f"BASELINE configs[4]: {n_stream} volumes per rank streamed through PrefetchingStream into a consumer "
+                          f"that touches every image ({args.size}^3, 4 cached subjects per rank)", "scaling": "weak",
+              "volumes_per_rank": n_stream}
+        for key, kw in (("cpu_contract", dict(to_host=True, depth=3)), ("device_resident", dict(to_host=False))):
+            acc = torch.zeros((), dtype=torch.float64, device=device)
+            host_acc = 0.0
+            for item in PrefetchingStream(ds, idx[:8], base_seed=99, **kw):  # warm-up (ring allocation, pinning)
+                pass
+            torch.cuda.synchronize()
+            R.barrier()
+            t0 = time.perf_counter()
+            for item in PrefetchingStream(ds, idx, base_seed=99, **kw):
+                img = item["image"]
+                if img.is_cuda:
+                    acc += img.view(-1)[::4097].sum()
+                else:
+                    host_acc += float(img.view(-1)[::4097].sum())
+            torch.cuda.synchronize()
+            R.barrier()
+            dts = R.max(time.perf_counter() - t0)
+            c5[key] = {"volumes_per_s": round(world * n_stream / dts, 1), "s": round(dts, 3),
+                       "outputs": ("float32 image (1,H,W,D) + int64 labels on the CPU (pinned ring), reference data/datasets.py:315-323"
+                                   if key == "cpu_contract" else "float32 image + uint8 labels in HBM")}
+        del ds
+
+    reports = R.gather({"rank": rank, "device": device, "name": props.name, "uuid": str(getattr(props, "uuid", "")) or None,
+                        "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid(),
+                        "volumes_per_s": round(args.steps / dt_rank, 1)})
     if rank == 0:
-        if not args.no_microbench:
-            result["blur_microbench"] = blur_microbench(shape, device)
+        result["ranks_seen"] = sorted(r["rank"] for r in reports)
+        result["ranks"] = reports
+        if c3 is not None:
+            result["config3"] = c3
+        if c5 is not None:
+            result["config5"] = c5
+            result["value_cpu_contract"] = c5["cpu_contract"]["volumes_per_s"]
         if world == 1 and not args.no_sr:
             result["config4_sr"] = config4_sr(device)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             result["cpu_baseline"] = cpu_baseline(shape, threads)
             result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+            result["gpu_over_reference_anchor"] = round(result["value"] / REFERENCE_ANCHOR["value"], 1)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    R.close()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)  # parent of N ranks: no GPU call in this process
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or unset "
+                         "WORLD_SIZE to let bench.py start its own ranks")
+    return run(args, rank, world, local)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

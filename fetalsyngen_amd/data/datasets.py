@@ -43,6 +43,15 @@ class SeedBank:
     def shape(self):
         return tuple(next(iter(next(iter(self.vol.values())).values())).shape)
 
+    def transformed(self, fn) -> "SeedBank":
+        """A new bank whose volumes are `fn(volume)` of this one's (device-side, e.g. a roll or a flip: a cheap way to
+        more distinct synthetic subjects)."""
+        other = SeedBank.__new__(SeedBank)
+        other.device = self.device
+        other.vol = {n: {m: fn(v).contiguous() for m, v in d.items()} for n, d in self.vol.items()}
+        other._cache = {}
+        return other
+
     def combined(self, mlabel2subclusters: dict) -> torch.Tensor:
         key = tuple(sorted(mlabel2subclusters.items()))
         hit = self._cache.get(key)
@@ -211,3 +220,29 @@ class FetalSynthDataset(FetalDataset):
         data, generation_params = self.sample(idx, genparams=genparams)
         data["generation_params"] = generation_params
         return data
+
+
+class MemorySynthDataset(FetalSynthDataset):
+    """`FetalSynthDataset` over label volumes that are already decoded (no BIDS tree, no files): subject k is
+    `(segmentations[k], seed_volumes[k])` with `seed_volumes[k][n_sub][mlabel] -> integer array`, uploaded once.
+    Same `sample` / `__getitem__` / `sample_with_meta` contract; used by the synthetic-label benchmarks
+    (BASELINE configs 2, 3, 5) and wherever the labels come from somewhere other than NIfTI files."""
+
+    def __init__(self, generator: FetalSynthGen, segmentations, seed_volumes, return_device: bool = False,
+                 names=None):
+        if len(segmentations) != len(seed_volumes) or not len(segmentations):
+            raise ValueError("need one seed-volume table per segmentation (and at least one subject)")
+        self.bids_path, self.seed_path = Path("<memory>"), Path("<memory>")
+        self.subjects = list(names) if names is not None else [f"sub-mem{k:03d}" for k in range(len(segmentations))]
+        self.sub_ses = [(s, None) for s in self.subjects]
+        self.loader = NiftiReader()
+        self.img_paths = self.segm_paths = ["<memory>"] * len(self.subjects)
+        self.load_image, self.image_as_intensity = False, False
+        self.generator = generator
+        self.cache_on_device, self.return_device = True, return_device
+        self._banks, self._segs = {}, {}
+        dev = generator.device
+        for k, (seg, vols) in enumerate(zip(segmentations, seed_volumes)):
+            d = torch.as_tensor(np.asarray(seg) if not torch.is_tensor(seg) else seg).float().to(dev).contiguous()
+            self._segs[k] = (d, d.to(torch.uint8))
+            self._banks[self.subjects[k]] = vols if isinstance(vols, SeedBank) else SeedBank(vols, dev)

@@ -298,6 +298,27 @@ class FetalSynthGen:
         out, seg, img, params = self._pipeline(image, segmentation, seeds, genparams, scale01=False)
         return out, seg, img, params
 
+    def _draw_plans(self, shape, genparams):
+        """Host draws of everything after the intensity plan, in the reference's order:
+        deformation, gamma, bias field, resampling, noise.  No device work."""
+        dplan = self.spatial_deform.plan(shape, random_shift=True, genparams=genparams.get("deform_params", {}))
+        g = self.gamma.plan(genparams.get("gamma_params", {}))
+        bplan = self.biasfield.plan(shape, genparams.get("bf_params", {}))
+        res = self.__dict__.get("_res64")
+        if res is None:
+            res = self._res64 = np.array(self.resolution)
+        rplan = self.resampled.plan(shape, res, genparams.get("resample_params", {}))
+        low_shape = rplan.new_size if rplan.active else shape
+        nplan = self.noise.plan(low_shape, genparams.get("noise_params", {}))
+        return dplan, g, bplan, rplan, nplan
+
+    def plan_only(self, shape, genparams: dict = {}):
+        """Every host draw of one seeds-based sample, nothing enqueued (bench.py --dry-plan, host profiling)."""
+        with _rng.use(self.rng):
+            m2s = self.intensity_generator.draw_subclusters(genparams.get("selected_seeds", {}))
+            gmm_plan = self.intensity_generator.plan_intensities(tuple(shape), genparams.get("seed_intensities", {}))
+            return (m2s, gmm_plan) + self._draw_plans(tuple(shape), genparams)
+
     def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
         if genparams:
             genparams = self._validated_genparams(genparams)
@@ -321,12 +342,7 @@ class FetalSynthGen:
                     raise ValueError(
                         "If no seeds are passed, an image must be loaded to be used as intensity prior!")
                 shape = tuple(image.shape)
-            dplan = sd.plan(shape, random_shift=True, genparams=genparams.get("deform_params", {}))
-            g = self.gamma.plan(genparams.get("gamma_params", {}))
-            bplan = self.biasfield.plan(shape, genparams.get("bf_params", {}))
-            rplan = self.resampled.plan(shape, np.array(self.resolution), genparams.get("resample_params", {}))
-            low_shape = rplan.new_size if rplan.active else shape
-            nplan = self.noise.plan(low_shape, genparams.get("noise_params", {}))
+            dplan, g, bplan, rplan, nplan = self._draw_plans(shape, genparams)
 
             # ---------------- one upload of all small arrays ------------------------------------
             arena = T.Arena()
