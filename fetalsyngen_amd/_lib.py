@@ -100,6 +100,7 @@ P, I, F, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
     "fsg_abi_version": [],
     "fsg_set_tuning": [I],
+    "fsg_warp_set_variant": [I],
     "fsg_randn_f32": [P, SZ, U64, U64, P],
     "fsg_gmm_sample_u8": [P, SZ, P, P, I, P, U64, U64, P, P],
     "fsg_gmm_sample_i64": [P, SZ, P, P, I, P, U64, U64, P, P],

@@ -234,6 +234,53 @@ static inline int fsg_fill_deform(const fsg_deform* d, FsgDeformK& K) {
   return 0;
 }
 
+// kernel-argument copy of fsg_epilogue
+struct EpiK {
+  float gamma;
+  int b0, b1, b2;
+  const float* bias;
+  const fsg_tap* bx;
+  const fsg_tap* by;
+  const fsg_tap* bz;
+};
+
+static inline int fill_epilogue(const fsg_epilogue* e, EpiK& K) {
+  K.gamma = 0.f; K.bias = nullptr; K.bx = K.by = K.bz = nullptr; K.b0 = K.b1 = K.b2 = 0;
+  if (!e) return 0;
+  K.gamma = e->gamma;
+  if (e->bias) {
+    if (!e->bx || !e->by || !e->bz) return FSG_E_BADARG;
+    K.bias = e->bias; K.bx = e->bx; K.by = e->by; K.bz = e->bz;
+    K.b0 = e->bias_dims[0]; K.b1 = e->bias_dims[1]; K.b2 = e->bias_dims[2];
+    if (K.b0 <= 0 || K.b1 <= 0 || K.b2 <= 0) return FSG_E_BADARG;
+  }
+  return 0;
+}
+
+// floor(min) of the clamped coordinates per axis (affine_nonrigid.py:350-358), from the order keys of the reduction
+struct Margins { float mx, my, mz; };
+
+__device__ __forceinline__ Margins load_margins(const int32_t* mm6) {
+  Margins m;
+  m.mx = floorf(fsg_key2f(mm6[0]));
+  m.my = floorf(fsg_key2f(mm6[1]));
+  m.mz = floorf(fsg_key2f(mm6[2]));
+  return m;
+}
+
+// logical tile id: hardware deals consecutive workgroups round-robin over the 8 XCDs; give every XCD a
+// contiguous range of tiles (= a slab of x planes) so the source planes it gathers from stay in ITS L2.
+// Speed only: any mapping gives the same result.
+__device__ __forceinline__ int xcd_tile(int b, int nb) {
+  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
+// fsg_warp_lean.hip: the lean fused warp (-> FSG_E_ALIGN when the configuration is outside its domain).
+// label_in_bytes / label_out_bytes: 4 = float32, 1 = uint8.
+int fsg_launch_warp_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const float* src_lin, float* out_lin,
+                         const void* src_nn, void* out_nn, int label_in_bytes, int label_out_bytes, bool fast,
+                         void* stream);
+
 // launch geometry: x = 64 lanes along z, y = 4 rows along y; grid (z chunks, y chunks, x)
 static inline dim3 fsg_block3() { return dim3(64, 4, 1); }
 static inline dim3 fsg_grid3(int n0, int n1, int n2) {

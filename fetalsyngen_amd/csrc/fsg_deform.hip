@@ -11,18 +11,9 @@
 #include "fsg_common.h"
 
 int g_tuning_flags = 0;  // FSG_TUNE_* bits, see fsg_set_tuning
+int g_warp_variant = 0;   // fsg_warp_set_variant
 
 namespace {
-
-struct Margins { float mx, my, mz; };
-
-__device__ __forceinline__ Margins load_margins(const int32_t* mm6) {
-  Margins m;
-  m.mx = floorf(fsg_key2f(mm6[0]));
-  m.my = floorf(fsg_key2f(mm6[1]));
-  m.mz = floorf(fsg_key2f(mm6[2]));
-  return m;
-}
 
 // ---- min/max of the clamped coordinates (affine_nonrigid.py:350-355) -------------------------
 __global__ __launch_bounds__(256) void coords_minmax_kernel(FsgDeformK D, int32_t* __restrict__ mm6) {
@@ -110,15 +101,6 @@ __device__ __forceinline__ T sample_nearest(const T* __restrict__ s, const FsgDe
   zi = min(max(zi, 0), D.n2 - 1);
   return fetch(s, D, xi, yi, zi);
 }
-
-struct EpiK {
-  float gamma;
-  int b0, b1, b2;
-  const float* bias;
-  const fsg_tap* bx;
-  const fsg_tap* by;
-  const fsg_tap* bz;
-};
 
 // =================================================================================================
 // Row-wise kernels (the tuned path).  One wave owns one output row (i, j, all k) at a time:
@@ -230,9 +212,6 @@ __device__ __forceinline__ float sample_linear_pairs(const float* __restrict__ s
 // logical tile id: hardware deals consecutive workgroups round-robin over the 8 XCDs; give every XCD a
 // contiguous range of tiles (= a slab of x planes) so the source planes it gathers from stay in ITS L2.
 // Speed only: any mapping gives the same result.
-__device__ __forceinline__ int xcd_tile(int b, int nb) {
-  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-}
 
 // ---- per-row coarse values, precomputed once per deformation ------------------------------------------
 // rows[(i*n1 + j)*stride + e]: e < 3*f2 -> x/y-interpolated displacement (channel-major, then z index of
@@ -857,6 +836,77 @@ __global__ __launch_bounds__(1024, 8) void warp_patch_kernel(FsgDeformK D, const
   }
 }
 
+// ---- tile variant: the 16 waves sweep a PI x PJ patch of rows in lockstep, KZ voxels of every row per step ------
+// The patch kernel above gives a wave 64 consecutive z voxels of ONE row: at the rotations the generator draws
+// (<= 20 degrees about every axis) the source positions of such a run drift by up to 64 * sin(theta) = 13-20 source
+// rows in x and in y, so one gather touches ~30 different 128-B lines and uses a few voxels of each.  Here a wave
+// covers RJ = 64 / KZ adjacent rows x KZ voxels: the drift inside a step is KZ * sin(theta), the footprint of the
+// workgroup's PI x PJ x KZ brick of outputs is a compact block of source rows that the next step (same rows, next
+// KZ voxels) continues along the same cache lines.  Same per-voxel arithmetic (warp_emitN), bit-identical output.
+template <typename LT, bool HAS_LIN, bool HAS_NN, bool FAST, int KZ, int WI>
+__global__ __launch_bounds__(1024, 8) void warp_tile_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+                                                         const float* __restrict__ src_lin,
+                                                         float* __restrict__ out_lin,
+                                                         const LT* __restrict__ src_nn, LT* __restrict__ out_nn,
+                                                         EpiK E) {
+  constexpr int RJ = 64 / KZ;   // rows (along j) per wave
+  constexpr int WJ = 16 / WI;   // waves along j
+  constexpr int PI = WI, PJ = WJ * RJ;
+  __shared__ float sm_all[PI * PJ][PATCH_ROWCAP];
+  __shared__ int4 s_tz[PATCH_TZCAP], s_bz[PATCH_TZCAP];
+  const bool taps_lds = D.n2 <= PATCH_TZCAP;
+  if (taps_lds) {
+    for (int t = threadIdx.x; t < D.n2; t += 1024) {
+      if (D.field) s_tz[t] = *reinterpret_cast<const int4*>(D.tz + t);
+      if (E.bias) s_bz[t] = *reinterpret_cast<const int4*>(E.bz + t);
+    }
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tiles_j = (D.n1 + PJ - 1) / PJ;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int wi = wave / WJ, wj = wave - wi * WJ;
+  const int i_raw = (tile / tiles_j) * PI + wi;
+  const int j_wave = (tile % tiles_j) * PJ + wj * RJ;
+  const int rj = lane / KZ, kz = lane - rj * KZ;
+  const int j_raw = j_wave + rj;
+  const bool live_row = i_raw < D.n0 && j_raw < D.n1;
+  const int i = min(i_raw, D.n0 - 1), j = min(j_raw, D.n1 - 1);
+  const Margins m = load_margins(mm6);
+  const int nf = D.field ? 3 * D.f2 : 0;
+  const int need = nf + (E.bias ? E.b2 : 0);
+  const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
+  if (need) {
+    const bool onfly = D.rows == nullptr;
+    const fsg_tap ax = (onfly && D.field) ? uniform_tap(D.tx, i) : none;
+    const fsg_tap abx = (onfly && E.bias) ? uniform_tap(E.bx, i) : none;
+#pragma unroll
+    for (int r = 0; r < RJ; ++r)  // every row of the wave is staged by all 64 lanes
+      stage_row(D, E, i, min(j_wave + r, D.n1 - 1), nf, need, ax, abx, sm_all[wave * RJ + r], lane);
+  }
+  __syncthreads();
+  const float* sm = sm_all[wave * RJ + rj];
+  const size_t row = ((size_t)i * D.n1 + j) * D.n2;
+  auto tap_at = [&](const int4* lds, const fsg_tap* tab, bool on, int k) {
+    fsg_tap c = none;
+    if (on) {
+      if (taps_lds) { const int4 v = lds[k]; c = fsg_tap{v.x, v.y, __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)}; }
+      else c = tab[k];
+    }
+    return c;
+  };
+  for (int kb = 0; kb < D.n2; kb += KZ) {
+    const int kk = kb + kz;
+    const int k = min(kk, D.n2 - 1);
+    fsg_tap ck[4] = {none, none, none, none}, cbk[4] = {none, none, none, none};
+    ck[0] = tap_at(s_tz, D.tz, D.field != nullptr, k);
+    cbk[0] = tap_at(s_bz, E.bz, E.bias != nullptr, k);
+    // lanes past the end of the row or of the patch recompute a live voxel and do not store (kbase >= n2 disables stores)
+    warp_emitN<LT, HAS_LIN, HAS_NN, FAST, 0, 1>(D, E, m, sm, nf, i, j, (live_row && kk < D.n2) ? kk : (D.n2 + kk), ck, cbk, row,
+                                                src_lin, out_lin, src_nn, out_nn);
+    __syncthreads();  // the 16 waves stay on the same z slab: the brick's source block is what L1 holds
+  }
+}
+
 template <bool MIN_ONLY>
 __global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, int32_t* __restrict__ mm6,
                                                                  int rows_per_block) {
@@ -1279,18 +1329,6 @@ __global__ __launch_bounds__(256) void warp_brick_kernel(FsgDeformK D, const int
   }
 }
 
-int fill_epilogue(const fsg_epilogue* e, EpiK& K) {
-  K.gamma = 0.f; K.bias = nullptr; K.bx = K.by = K.bz = nullptr; K.b0 = K.b1 = K.b2 = 0;
-  if (!e) return 0;
-  K.gamma = e->gamma;
-  if (e->bias) {
-    if (!e->bx || !e->by || !e->bz) return FSG_E_BADARG;
-    K.bias = e->bias; K.bx = e->bx; K.by = e->by; K.bz = e->bz;
-    K.b0 = e->bias_dims[0]; K.b1 = e->bias_dims[1]; K.b2 = e->bias_dims[2];
-    if (K.b0 <= 0 || K.b1 <= 0 || K.b2 <= 0) return FSG_E_BADARG;
-  }
-  return 0;
-}
 
 template <typename LT>
 int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, float* out_lin, const LT* src_nn,
@@ -1308,12 +1346,44 @@ int launch_warp(const fsg_deform* d, const int32_t* mm6, const float* src_lin, f
   if (rc) return rc;
   const int need = (D.field ? 3 * D.f2 : 0) + (E.bias ? E.b2 : 0);
   if (D.rows && D.row_stride < need) return FSG_E_BADARG;
+  if (g_warp_variant == 0 &&
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_WARP | FSG_TUNE_NO_PATCH | FSG_TUNE_BUFFER_LOADS | FSG_TUNE_NO_LEAN))) {
+    // default: the lean body (fsg_warp_lean.hip); FSG_E_ALIGN = configuration outside its domain
+    rc = fsg_launch_warp_lean(D, E, mm6, src_lin, out_lin, src_nn, out_nn, (int)sizeof(LT), (int)sizeof(LT),
+                              !(g_tuning_flags & FSG_TUNE_PRECISE_MATH), stream);
+    if (rc != FSG_E_ALIGN) return rc;
+  }
   if (need <= PATCH_ROWCAP && D.n2 >= 2 && !(g_tuning_flags & (FSG_TUNE_GENERIC_WARP | FSG_TUNE_NO_PATCH))) {
     const int ntiles = ((D.n0 + PATCH - 1) / PATCH) * ((D.n1 + PATCH - 1) / PATCH);
     const bool fast = !(g_tuning_flags & FSG_TUNE_PRECISE_MATH);
     const dim3 grid((unsigned)ntiles), block(1024);
     hipStream_t st = fsg_stream(stream);
     const bool buf = (g_tuning_flags & FSG_TUNE_BUFFER_LOADS) != 0;
+    if (g_warp_variant > 0) {
+      // lockstep tile variants (fsg_warp_set_variant): 1 = 8x8 rows x 16 voxels, 2 = 4x8 rows x 32, 3 = 8x4 rows x 32, 4 = 4x16 rows x 16
+#define FSG_LAUNCH_TILE(L, N, F, KZ, WI)                                                                                \
+  do {                                                                                                                 \
+    constexpr int PI_ = WI, PJ_ = (16 / WI) * (64 / KZ);                                                               \
+    const dim3 g((unsigned)(((D.n0 + PI_ - 1) / PI_) * ((D.n1 + PJ_ - 1) / PJ_)));                                     \
+    hipLaunchKernelGGL((warp_tile_kernel<LT, L, N, F, KZ, WI>), g, block, 0, st, D, mm6, src_lin, out_lin, src_nn,     \
+                       out_nn, E);                                                                                     \
+  } while (0)
+#define FSG_LAUNCH_TILE_V(L, N, F)                      \
+  do {                                                  \
+    switch (g_warp_variant) {                           \
+      case 1: FSG_LAUNCH_TILE(L, N, F, 16, 8); break;   \
+      case 2: FSG_LAUNCH_TILE(L, N, F, 32, 4); break;   \
+      case 3: FSG_LAUNCH_TILE(L, N, F, 32, 8); break;   \
+      default: FSG_LAUNCH_TILE(L, N, F, 16, 4); break;  \
+    }                                                   \
+  } while (0)
+      if (src_lin && src_nn) { if (fast) FSG_LAUNCH_TILE_V(true, true, true); else FSG_LAUNCH_TILE_V(true, true, false); }
+      else if (src_lin)      { if (fast) FSG_LAUNCH_TILE_V(true, false, true); else FSG_LAUNCH_TILE_V(true, false, false); }
+      else                   { FSG_LAUNCH_TILE_V(false, true, true); }
+#undef FSG_LAUNCH_TILE_V
+#undef FSG_LAUNCH_TILE
+      FSG_RETURN_LAUNCH();
+    }
 #define FSG_LAUNCH_PATCH(L, N, F)                                                                                      \
   do {                                                                                                                 \
     if (buf)                                                                                                           \
@@ -1368,6 +1438,13 @@ int launch_warp_u8src(const fsg_deform* d, const int32_t* mm6, const float* src_
   EpiK E;
   rc = fill_epilogue(epi, E);
   if (rc) return rc;
+  if (g_warp_variant == 0 && sizeof(LD) == 4 &&
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_WARP | FSG_TUNE_NO_PATCH | FSG_TUNE_BUFFER_LOADS | FSG_TUNE_NO_LEAN | FSG_TUNE_BRICK))) {
+    // uint8 labels in, float32 labels out: served by the lean kernel (the uint8 -> uint8 case reaches it through launch_warp)
+    rc = fsg_launch_warp_lean(D, E, mm6, src_lin, out_lin, src_nn, out_nn, 1, 4, !(g_tuning_flags & FSG_TUNE_PRECISE_MATH),
+                              stream);
+    if (rc != FSG_E_ALIGN) return rc;
+  }
   const uintptr_t al16 = (uintptr_t)src_lin | (uintptr_t)out_lin | (sizeof(LD) == 4 ? (uintptr_t)out_nn : 0);
   const uintptr_t al4 = (uintptr_t)src_nn | (sizeof(LD) == 1 ? (uintptr_t)out_nn : 0);
   if ((D.n2 & 3) || (al16 & 15) || (al4 & 3) || D.n2 < 4 || !(g_tuning_flags & FSG_TUNE_BRICK)) return FSG_E_ALIGN;
@@ -1416,6 +1493,12 @@ extern "C" {
 int fsg_set_tuning(int flags) {
   const int prev = g_tuning_flags;
   g_tuning_flags = flags;
+  return prev;
+}
+
+int fsg_warp_set_variant(int variant) {
+  const int prev = g_warp_variant;
+  if (variant >= 0 && variant <= 4) g_warp_variant = variant;
   return prev;
 }
 

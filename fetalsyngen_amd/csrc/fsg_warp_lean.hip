@@ -1,0 +1,220 @@
+// fsg_warp_lean.hip -- K3+K4(+K5): the fused warp with a lean per-voxel instruction stream.
+//
+// Same contract and the same fp32 operation order as warp_patch_kernel / warp_rows_kernel of fsg_deform.hip
+// (reference: affine_nonrigid.py:327-366 positions, utils/generation.py:204-288 samplers, synthseg.py:274 and
+// :178-182 epilogue) -- outputs are bit-identical (tests/test_hip_parity.py::test_warp_work_shapes_are_bit_identical).
+//
+// What is different is the cost per voxel.  The patch kernel issues ~230 vector instructions per 64 voxels and its
+// time follows that count (profiles/r02_warp_*.txt): it is bound by instruction issue, not by bytes.  This body
+// spends ~40 % fewer:
+//   * the per-row coarse displacement values sit in LDS as one float4 (dx, dy, dz, -) per coarse z index: two
+//     ds_read_b128 per voxel instead of six ds_read_b32 with six address computations;
+//   * sampling positions are clamped with v_med3_f32 (one instruction per axis instead of two compare/select
+//     pairs; a coordinate of -0.0 may come out as +0.0, which no consumer below distinguishes);
+//   * raw buffer loads / stores: a 32-bit byte offset per access, no 64-bit address arithmetic, and an
+//     out-of-range offset returns 0 instead of faulting -- so no index is clamped: indices are in range by
+//     construction, and where the reference clamps the upper neighbour onto the base (coordinate exactly on the
+//     last plane / row) that neighbour's weight is exactly 0, so the finite value (or the 0 of an out-of-range
+//     read) found there contributes +-0;
+//   * the axis-0 flip is folded into a signed plane stride and a base offset (no per-voxel select);
+//   * index products on v_mad_i32_i24 (full rate) instead of v_mul_lo_u32 (quarter rate);
+//   * work shape: the 16 waves of a workgroup sweep 8 x 4 adjacent rows, 32 voxels of each per lockstep step
+//     (fsg_warp_set_variant 3 of the patch kernel family, the fastest of the shapes measured).
+// Domain (else FSG_E_ALIGN and the caller falls back): per-row coarse values precomputed (fsg_deform_rows_f32),
+// coarse grids of at most 32 entries along z, shape[2] <= 512, shape[1]*shape[2] < 2^22, fewer than 2^30 voxels.
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int LEAN_F2CAP = 32;   // coarse displacement entries along z
+constexpr int LEAN_B2CAP = 32;   // coarse bias entries along z
+constexpr int LEAN_TZCAP = 512;  // z extent whose taps are staged in LDS
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ T lean_load_label(__amdgpu_buffer_rsrc_t r, unsigned elem);
+template <>
+__device__ __forceinline__ float lean_load_label<float>(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, elem * 4u, 0, 0));
+}
+template <>
+__device__ __forceinline__ uint8_t lean_load_label<uint8_t>(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_amdgcn_raw_buffer_load_b8(r, elem, 0, 0);
+}
+__device__ __forceinline__ void lean_store_label(__amdgpu_buffer_rsrc_t r, unsigned elem, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, elem * 4u, 0, 0);
+}
+__device__ __forceinline__ void lean_store_label(__amdgpu_buffer_rsrc_t r, unsigned elem, uint8_t v) {
+  __builtin_amdgcn_raw_buffer_store_b8(v, r, elem, 0, 0);
+}
+
+template <typename ST, typename DT, bool HAS_LIN, bool HAS_NN, bool FAST, int KZ, int WI>
+__global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
+                                                         const float* __restrict__ src_lin, float* __restrict__ out_lin,
+                                                         const ST* __restrict__ src_nn, DT* __restrict__ out_nn, EpiK E) {
+  constexpr int RJ = 64 / KZ;  // rows (along j) per wave
+  constexpr int WJ = 16 / WI;  // waves along j
+  constexpr int PI = WI, PJ = WJ * RJ, NROW = PI * PJ;
+  __shared__ float4 s_f[NROW][LEAN_F2CAP];  // x/y-interpolated coarse displacement of every row: (dx, dy, dz, -) per coarse z
+  __shared__ float s_b[NROW][LEAN_B2CAP];   // x/y-interpolated coarse bias of every row
+  __shared__ int4 s_tz[LEAN_TZCAP], s_bz[LEAN_TZCAP];  // z taps of the displacement / bias grids
+  const bool has_field = D.field != nullptr, has_bias = E.bias != nullptr;
+  for (int t = threadIdx.x; t < D.n2; t += 1024) {
+    if (has_field) s_tz[t] = *reinterpret_cast<const int4*>(D.tz + t);
+    if (has_bias) s_bz[t] = *reinterpret_cast<const int4*>(E.bz + t);
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tiles_j = (D.n1 + PJ - 1) / PJ;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int wi = wave / WJ, wj = wave - wi * WJ;
+  const int i_raw = (tile / tiles_j) * PI + wi;
+  const int j_wave = (tile % tiles_j) * PJ + wj * RJ;
+  const int rj = lane / KZ, kz = lane - rj * KZ;
+  const int j_raw = j_wave + rj;
+  const bool live_row = i_raw < D.n0 && j_raw < D.n1;
+  const int i = min(i_raw, D.n0 - 1), j = min(j_raw, D.n1 - 1);
+  const Margins m = load_margins(mm6);
+  const int nf = has_field ? 3 * D.f2 : 0;
+  // stage the wave's rows from the precomputed per-row values (channel-major there, interleaved here)
+#pragma unroll
+  for (int r = 0; r < RJ; ++r) {
+    const int jr = min(j_wave + r, D.n1 - 1);
+    const float* __restrict__ g = D.rows + ((size_t)i * D.n1 + jr) * D.row_stride;
+    float* dst = reinterpret_cast<float*>(&s_f[wave * RJ + r][0]);
+    if (has_field && lane < D.f2) {
+      dst[lane * 4 + 0] = g[lane];
+      dst[lane * 4 + 1] = g[D.f2 + lane];
+      dst[lane * 4 + 2] = g[2 * D.f2 + lane];
+    }
+    if (has_bias && lane < E.b2) s_b[wave * RJ + r][lane] = g[nf + lane];
+  }
+  __syncthreads();
+
+  const int rowid = wave * RJ + rj;
+  const float4* __restrict__ sf = s_f[rowid];
+  const float* __restrict__ sb = s_b[rowid];
+  const unsigned nvox = (unsigned)D.n0 * (unsigned)D.n1 * (unsigned)D.n2;
+  const __amdgpu_buffer_rsrc_t r_lin = __builtin_amdgcn_make_buffer_rsrc((void*)src_lin, 0, HAS_LIN ? nvox * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_olin = __builtin_amdgcn_make_buffer_rsrc((void*)out_lin, 0, HAS_LIN ? nvox * 4u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_nn =
+      __builtin_amdgcn_make_buffer_rsrc((void*)src_nn, 0, HAS_NN ? nvox * (unsigned)sizeof(ST) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_onn =
+      __builtin_amdgcn_make_buffer_rsrc((void*)out_nn, 0, HAS_NN ? nvox * (unsigned)sizeof(DT) : 0u, 0x00020000);
+  // element offset of source voxel (x, y, z) = base + x * sxs + y * sy + z, the flip folded into base / sxs
+  const int sy = D.n2;
+  const int sx = D.n1 * D.n2;
+  const int sxs = D.flip ? -sx : sx;
+  const int base = D.flip ? (D.n0 - 1) * sx : 0;
+  const int dxb = sxs * 4, oyb = sy * 4;  // byte strides towards the upper x / y neighbours
+  const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
+  const float pxb = (float)i - D.cen[0], pyb = (float)j - D.cen[1];
+  unsigned oelem = (unsigned)(((size_t)i * D.n1 + j) * D.n2) + (unsigned)kz;  // output element of this lane, step 0
+
+  for (int kb = 0; kb < D.n2; kb += KZ, oelem += KZ) {
+    const int kk = kb + kz;
+    const int k = min(kk, D.n2 - 1);
+    const bool live = live_row && kk < D.n2;
+    float px = pxb, py = pyb, pz = (float)k - D.cen[2];
+    if (has_field) {
+      const int4 c = s_tz[k];
+      const float wl = __builtin_bit_cast(float, c.z), wh = __builtin_bit_cast(float, c.w);
+      const float4 a = sf[c.x], b = sf[c.y];
+      px = px + (wl * a.x + wh * b.x);
+      py = py + (wl * a.y + wh * b.y);
+      pz = pz + (wl * a.z + wh * b.z);
+    }
+    float x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
+    float y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
+    float z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
+    x = __builtin_amdgcn_fmed3f(x, 0.f, hx) - m.mx;
+    y = __builtin_amdgcn_fmed3f(y, 0.f, hy) - m.my;
+    z = __builtin_amdgcn_fmed3f(z, 0.f, hz) - m.mz;
+    ST lab = 0;
+    if (HAS_NN) {
+      const int xi = (int)rintf(x), yi = (int)rintf(y), zi = (int)rintf(z);  // round half to even; in range by construction
+      const unsigned e = (unsigned)(base + __mul24(xi, sxs) + __mul24(yi, sy) + zi);
+      lab = lean_load_label<ST>(r_nn, e);  // stored after the blend: its latency overlaps the four gathers below
+    }
+    if (HAS_LIN) {
+      const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f);  // x <= n-1 etc. hold by construction (clamped)
+      const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+      const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+      const float bx = x - fx, by = y - fy, bz = z - fz;
+      const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
+      const unsigned o = (unsigned)(base + __mul24(x0, sxs) + __mul24(y0, sy) + z0) * 4u;
+      f2v p00 = {0.f, 0.f}, p10 = {0.f, 0.f}, p01 = {0.f, 0.f}, p11 = {0.f, 0.f};
+      if (ok) {  // voxels that sample outside the volume (clamped onto a 0-face) need no data
+        p00 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o, 0, 0));
+        p10 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)dxb, 0, 0));
+        p01 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)oyb, 0, 0));
+        p11 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)(dxb + oyb), 0, 0));
+      }
+      if (ok && z0 >= D.n2 - 1) {  // rare (z exactly on the last column): single-element reads, upper neighbour unused
+        p00.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o, 0, 0));
+        p10.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)dxb, 0, 0));
+        p01.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)oyb, 0, 0));
+        p11.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)(dxb + oyb), 0, 0));
+        p00.y = p00.x; p10.y = p10.x; p01.y = p01.x; p11.y = p11.x;
+      }
+      const float c00 = p00.x * ax + p10.x * bx;
+      const float c01 = p00.y * ax + p10.y * bx;
+      const float c10 = p01.x * ax + p11.x * bx;
+      const float c11 = p01.y * ax + p11.y * bx;
+      const float c0 = c00 * ay + c10 * by;
+      const float c1 = c01 * ay + c11 * by;
+      float v = ok ? (c0 * az + c1 * bz) : 0.f;
+      if (E.gamma > 0.f) {
+        // 300*(v/300)^g.  FAST: 300 * 2^(g*(log2 v - log2 300)) on v_log_f32 / v_exp_f32; else OCML powf and an IEEE division
+        if (FAST) v = 300.0f * __builtin_amdgcn_exp2f(E.gamma * (__builtin_amdgcn_logf(v) - 8.2288186904958804f));
+        else v = 300.0f * powf(v / 300.0f, E.gamma);
+      }
+      if (has_bias) {
+        const int4 cb = s_bz[k];
+        const float bval = fsg_mix(__builtin_bit_cast(float, cb.z), sb[cb.x], __builtin_bit_cast(float, cb.w), sb[cb.y]);
+        v = v * (FAST ? __builtin_amdgcn_exp2f(bval * 1.4426950408889634f) : expf(bval));
+      }
+      if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_olin, oelem * 4u, 0, 0);
+    }
+    if (HAS_NN && live) lean_store_label(r_onn, oelem, (DT)lab);
+    __syncthreads();  // the 16 waves stay on the same z slab: the brick's source block is what L1 holds
+  }
+}
+
+template <typename ST, typename DT>
+int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const float* src_lin, float* out_lin,
+                const ST* src_nn, DT* out_nn, bool fast, hipStream_t st) {
+  constexpr int KZ = 32, WI = 8;
+  constexpr int PI = WI, PJ = (16 / WI) * (64 / KZ);
+  const dim3 grid((unsigned)(((D.n0 + PI - 1) / PI) * ((D.n1 + PJ - 1) / PJ))), block(1024);
+#define FSG_LEAN(L, N, F) \
+  hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+  if (src_lin && src_nn) { if (fast) FSG_LEAN(true, true, true); else FSG_LEAN(true, true, false); }
+  else if (src_lin)      { if (fast) FSG_LEAN(true, false, true); else FSG_LEAN(true, false, false); }
+  else                   { FSG_LEAN(false, true, true); }
+#undef FSG_LEAN
+  FSG_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+int fsg_launch_warp_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const float* src_lin, float* out_lin,
+                         const void* src_nn, void* out_nn, int label_in_bytes, int label_out_bytes, bool fast,
+                         void* stream) {
+  const bool has_field = D.field != nullptr, has_bias = E.bias != nullptr;
+  const int need = (has_field ? 3 * D.f2 : 0) + (has_bias ? E.b2 : 0);
+  if (need > 0 && (!D.rows || D.row_stride < need)) return FSG_E_ALIGN;
+  if ((has_field && D.f2 > LEAN_F2CAP) || (has_bias && E.b2 > LEAN_B2CAP)) return FSG_E_ALIGN;
+  if (D.n2 < 2 || D.n2 > LEAN_TZCAP) return FSG_E_ALIGN;
+  const long long plane = (long long)D.n1 * D.n2, nvox = plane * D.n0;
+  if (plane >= (1ll << 22) || nvox >= (1ll << 30) || D.n0 >= (1 << 22)) return FSG_E_ALIGN;
+  hipStream_t st = fsg_stream(stream);
+  if (!src_nn) return launch_lean<float, float>(D, E, mm6, src_lin, out_lin, nullptr, nullptr, fast, st);
+  if (label_in_bytes == 4 && label_out_bytes == 4)
+    return launch_lean<float, float>(D, E, mm6, src_lin, out_lin, (const float*)src_nn, (float*)out_nn, fast, st);
+  if (label_in_bytes == 1 && label_out_bytes == 1)
+    return launch_lean<uint8_t, uint8_t>(D, E, mm6, src_lin, out_lin, (const uint8_t*)src_nn, (uint8_t*)out_nn, fast, st);
+  if (label_in_bytes == 1 && label_out_bytes == 4)
+    return launch_lean<uint8_t, float>(D, E, mm6, src_lin, out_lin, (const uint8_t*)src_nn, (float*)out_nn, fast, st);
+  return FSG_E_BADARG;
+}

@@ -79,8 +79,12 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_NO_BLUR_FUSE 1024 /* blur: y and z passes as two launches */
 #define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
 #define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
+#define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
+/* Work shape of the fused warp kernel (speed only, results identical): 0 = 4x4 rows x 64 voxels per lockstep step,
+ * 1 = 8x8 rows x 16 voxels, 2 = 4x8 rows x 32, 3 = 8x4 rows x 32, 4 = 4x16 rows x 16.  Returns the previous value. */
+int fsg_warp_set_variant(int variant);
 
 /* ---- RNG ------------------------------------------------------------------------------------ */
 /* Standard-normal field from Philox4x32-10 keyed (seed, stream_id), element e uses counter e/4,
@@ -184,9 +188,10 @@ int fsg_warp_f32_u8(const fsg_deform* d_host, const int32_t* mm6, const float* s
                     const uint8_t* src_nn, uint8_t* out_nn, const fsg_epilogue* epi_host, void* stream);
 
 /* Label volume read as uint8, deformed labels written as float32 (exact for 0..255): the reference keeps
- * segmentations as float32 tensors, the device-resident copy is uint8.  Served by the LDS brick kernel only
- * (FSG_TUNE_BRICK set, shape[2] % 4 == 0, 16-byte aligned fp32 volumes); returns FSG_E_ALIGN otherwise and
- * the caller uses fsg_warp_f32 / fsg_warp_f32_u8. */
+ * segmentations as float32 tensors, the device-resident copy is uint8.  Served by the lean warp kernel (per-row
+ * coarse values prepared, coarse grids <= 32 entries along z, shape[2] <= 512) or, with FSG_TUNE_BRICK, by the LDS
+ * brick kernel (shape[2] % 4 == 0, 16-byte aligned fp32 volumes); returns FSG_E_ALIGN otherwise and the caller
+ * uses fsg_warp_f32 / fsg_warp_f32_u8. */
 int fsg_warp_f32_u8_to_f32(const fsg_deform* d_host, const int32_t* mm6, const float* src_lin, float* out_lin,
                            const uint8_t* src_nn, float* out_nn, const fsg_epilogue* epi_host, void* stream);
 

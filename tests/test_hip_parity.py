@@ -662,6 +662,70 @@ def test_brick_kernel_equals_row_kernel(K, case):
 
 
 # ---- the other entry modes of FetalSynthGen.sample ----------------------------------------------------
+@pytest.mark.parametrize("shape", [(50, 37, 70), (64, 64, 64), (33, 72, 130)])
+def test_warp_work_shapes_are_bit_identical(K, shape):
+    """fsg_warp_set_variant only changes which voxels a wave processes together: every variant must reproduce the
+    default kernel bit for bit (image with gamma + bias epilogue, f32 and u8 labels, both flips, ragged shapes)."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import tables as T
+    from fetalsyngen_amd.utils.generation import make_affine_matrix
+
+    lib = _lib.load()
+    rs = np.random.RandomState(11)
+    img = (rs.rand(*shape) * 255).astype(np.float32)
+    lab = rs.randint(0, 8, shape).astype(np.float32)
+    A = make_affine_matrix([0.2, -0.17, 0.22], [0.01, -0.02, 0.015], [1.05, 0.95, 1.02]).astype(np.float32)
+    fdim = (5, 4, 6)
+    fs = dev((rs.randn(*fdim, 3) * 2.0).astype(np.float32))
+    ft, _ = T.zoom_tables(fdim, np.array(shape) / np.array(fdim))
+    bdim = (2, 3, 2)
+    bias = dev((rs.randn(*bdim) * 0.2).astype(np.float32))
+    bt, _ = T.zoom_tables(bdim, np.array(shape) / np.array(bdim))
+    c = (np.array(shape) - 1) / 2
+    res = {}
+    prev = lib.fsg_warp_set_variant(0)
+    try:
+        for variant in (0, 1, 2, 3, 4):
+            lib.fsg_warp_set_variant(variant)
+            for flip in (False, True):
+                spec = K.DeformSpec(shape, A, c, c.astype(np.float32), flip, fs, K.DeviceTables(ft, DEV), device=DEV)
+                spec.prepare_rows(bias, K.DeviceTables(bt, DEV))
+                mm6 = K.coords_minmax(spec)
+                out, seg = K.warp(spec, mm6, src_lin=dev(img), src_nn=dev(lab), gamma=1.13, bias=bias,
+                                  bias_tabs=K.DeviceTables(bt, DEV))
+                _, seg8 = K.warp(spec, mm6, src_nn=dev(lab.astype(np.uint8)))
+                plain, _ = K.warp(spec, mm6, src_lin=dev(img))
+                out2, seg8f = K.warp(spec, mm6, src_lin=dev(img), src_nn=dev(lab.astype(np.uint8)), gamma=1.13, bias=bias,
+                                     bias_tabs=K.DeviceTables(bt, DEV), nn_out=torch.float32)
+                res[(variant, flip)] = (host(out), host(seg), host(seg8), host(plain), host(out2), host(seg8f))
+        # variant 0 = the lean body (fsg_warp_lean.hip); the same with the r01 patch body and precise math
+        lib.fsg_warp_set_variant(0)
+        for key, flags in (("patch", 4096), ("lean_precise", 2), ("patch_precise", 4096 | 2)):
+            pf = lib.fsg_set_tuning(flags)
+            try:
+                for flip in (False, True):
+                    spec = K.DeformSpec(shape, A, c, c.astype(np.float32), flip, fs, K.DeviceTables(ft, DEV), device=DEV)
+                    spec.prepare_rows(bias, K.DeviceTables(bt, DEV))
+                    mm6 = K.coords_minmax(spec)
+                    out, seg = K.warp(spec, mm6, src_lin=dev(img), src_nn=dev(lab), gamma=1.13, bias=bias,
+                                      bias_tabs=K.DeviceTables(bt, DEV))
+                    res[(key, flip)] = (host(out), host(seg))
+            finally:
+                lib.fsg_set_tuning(pf)
+    finally:
+        lib.fsg_warp_set_variant(prev)
+    for flip in (False, True):
+        base = res[(0, flip)]
+        assert np.array_equal(base[1].astype(np.uint8), base[2]) and np.array_equal(base[1], base[5])
+        assert np.array_equal(base[0], base[4])
+        for variant in (1, 2, 3, 4):
+            for a, b in zip(res[(variant, flip)], base):
+                assert np.array_equal(a, b), (variant, flip)
+        assert np.array_equal(res[("patch", flip)][0], base[0]) and np.array_equal(res[("patch", flip)][1], base[1])
+        assert np.array_equal(res[("lean_precise", flip)][0], res[("patch_precise", flip)][0])
+        assert np.array_equal(res[("lean_precise", flip)][1], base[1])
+
+
 def _phantom_image(shape):
     g = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
     return (100 * np.exp(-(g[0] ** 2 + 1.5 * g[1] ** 2 + 2 * g[2] ** 2)) + 20 * np.sin(5 * g[0] * g[1]) + 30).astype(np.float32)

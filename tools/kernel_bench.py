@@ -18,10 +18,12 @@ ap.add_argument("--only", default="")
 ap.add_argument("--m", type=int, default=171, help="low-res size for the resample kernels")
 ap.add_argument("--rot", type=float, default=12.0, help="rotation (degrees) about each axis")
 ap.add_argument("--tune", type=int, default=0, help="fsg_set_tuning flags")
+ap.add_argument("--variant", type=int, default=0, help="fsg_warp_set_variant")
 args = ap.parse_args()
 dev = "cuda:0"
 from fetalsyngen_amd import _lib
 _lib.load().fsg_set_tuning(args.tune)
+_lib.load().fsg_warp_set_variant(args.variant)
 n = args.size
 shape = (n, n, n)
 N = n ** 3
@@ -78,6 +80,7 @@ specw.prepare_rows(bias, btabs)
 timeit("coords_minmax_ws", lambda: K.coords_minmax(specw), 0)
 timeit("warp_f32_f32_epi_ws", lambda: K.warp(specw, mm6, src_lin=img, src_nn=segf, gamma=1.1, bias=bias, bias_tabs=btabs), 16 * N)
 timeit("warp_f32_u8_epi_ws", lambda: K.warp(specw, mm6, src_lin=img, src_nn=seg8, gamma=1.1, bias=bias, bias_tabs=btabs), 10 * N)
+timeit("warp_f32_u8tof32_epi_ws", lambda: K.warp(specw, mm6, src_lin=img, src_nn=seg8, gamma=1.1, bias=bias, bias_tabs=btabs, nn_out=torch.float32), 13 * N)
 timeit("warp_lin_only_ws", lambda: K.warp(specw, mm6, src_lin=img), 8 * N)
 timeit("warp_nn_f32_only_ws", lambda: K.warp(specw, mm6, src_nn=segf), 8 * N)
 
