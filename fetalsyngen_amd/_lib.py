@@ -90,6 +90,8 @@ class SamplePlan(C.Structure):
         ("out", C.c_void_p),
         ("ev_blur_begin", C.c_void_p),
         ("ev_blur_end", C.c_void_p),
+        ("mm_slots", C.c_void_p),
+        ("mm_nslots", C.c_int32),
     ]
 
 
@@ -112,6 +114,8 @@ SIGNATURES = {
     "fsg_zoom3d_minmax_f32": [P, I, I, I, P, P, P, I, I, I, P, P],
     "fsg_zoom3d_normalise_f32": [P, I, I, I, P, P, P, P, I, I, I, P, I, P],
     "fsg_minmax_init": [P, I, I, P],
+    "fsg_zoom3d_minmax_sharded_f32": [P, I, I, I, P, P, P, I, I, I, P, I, P],
+    "fsg_zoom3d_normalise_sharded_f32": [P, I, I, I, P, P, P, P, I, I, I, P, I, I, P],
     "fsg_deform_rows_f32": [C.POINTER(Deform), C.POINTER(Epilogue), P, I, P],
     "fsg_coords_minmax_f32": [C.POINTER(Deform), P, P],
     "fsg_coords_floormin_f32": [C.POINTER(Deform), P, P],

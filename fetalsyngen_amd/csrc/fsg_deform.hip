@@ -1496,9 +1496,13 @@ int fsg_set_tuning(int flags) {
   return prev;
 }
 
+extern int g_lean_pace, g_lean_ablate;
 int fsg_warp_set_variant(int variant) {
   const int prev = g_warp_variant;
-  if (variant >= 0 && variant <= 4) g_warp_variant = variant;
+  g_lean_ablate = 0;
+  if (variant == 8 || variant == 9) { g_warp_variant = 0; g_lean_pace = 1; g_lean_ablate = variant - 7; }
+  if (variant >= 0 && variant <= 4) { g_warp_variant = variant; g_lean_pace = 1; }
+  if (variant >= 5 && variant <= 7) { g_warp_variant = 0; g_lean_pace = variant == 5 ? 0 : (variant == 6 ? 2 : 1); }
   return prev;
 }
 

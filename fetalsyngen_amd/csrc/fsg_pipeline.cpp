@@ -117,6 +117,13 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     const int m0 = p->low_shape[0], m1 = p->low_shape[1], m2 = p->low_shape[2];
     FSG_TRY(fsg_resample_noise_f32(cur, n0, n1, n2, p->rs_tab[0], p->rs_tab[1], p->rs_tab[2], p->ws_low, m0, m1, m2,
                                    p->noise_mode, p->noise, p->noise_seed, p->noise_stream, p->noise_std, stream));
+    if (p->mm_slots && p->mm_nslots >= 2 && p->mm_nslots <= 64) {  // keys sharded over slots: no contended address
+      FSG_TRY(fsg_zoom3d_minmax_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1,
+                                            n2, p->mm_slots, p->mm_nslots, stream));
+      FSG_TRY(fsg_zoom3d_normalise_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out,
+                                               n0, n1, n2, p->mm_slots, p->mm_nslots, p->scale01 ? 1 : 0, stream));
+      return 0;
+    }
     FSG_TRY(fsg_zoom3d_minmax_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1, n2,
                                   p->mm8 + 3, stream));
     FSG_TRY(fsg_zoom3d_normalise_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out, n0,

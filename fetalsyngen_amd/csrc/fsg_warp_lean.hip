@@ -24,6 +24,9 @@
 // coarse grids of at most 32 entries along z, shape[2] <= 512, shape[1]*shape[2] < 2^22, fewer than 2^30 voxels.
 #include "fsg_common.h"
 
+int g_lean_ablate = 0;  // 1 / 2: the diagnostic kernels (ABL), never set by the product
+int g_lean_pace = 1;  // lockstep barrier: 1 = every step, 2 = every second step, 0 = none (fsg_warp_set_variant 5..7)
+
 namespace {
 
 constexpr int LEAN_F2CAP = 32;   // coarse displacement entries along z
@@ -49,10 +52,13 @@ __device__ __forceinline__ void lean_store_label(__amdgpu_buffer_rsrc_t r, unsig
   __builtin_amdgcn_raw_buffer_store_b8(v, r, elem, 0, 0);
 }
 
-template <typename ST, typename DT, bool HAS_LIN, bool HAS_NN, bool FAST, int KZ, int WI>
+// ABL (diagnostic builds only, tools/warp_ab.sh): 1 = every vector-memory access predicated off at run time (arithmetic and
+// LDS traffic only), 2 = trivial sampling positions (memory traffic and blends only).  0 in every product launch.
+template <typename ST, typename DT, bool HAS_LIN, bool HAS_NN, bool FAST, int KZ, int WI, int ABL = 0>
 __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
                                                          const float* __restrict__ src_lin, float* __restrict__ out_lin,
-                                                         const ST* __restrict__ src_nn, DT* __restrict__ out_nn, EpiK E) {
+                                                         const ST* __restrict__ src_nn, DT* __restrict__ out_nn, EpiK E,
+                                                         int pace) {
   constexpr int RJ = 64 / KZ;  // rows (along j) per wave
   constexpr int WJ = 16 / WI;  // waves along j
   constexpr int PI = WI, PJ = WJ * RJ, NROW = PI * PJ;
@@ -109,14 +115,24 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
   const int dxb = sxs * 4, oyb = sy * 4;  // byte strides towards the upper x / y neighbours
   const float hx = (float)(D.n0 - 1), hy = (float)(D.n1 - 1), hz = (float)(D.n2 - 1);
   const float pxb = (float)i - D.cen[0], pyb = (float)j - D.cen[1];
-  unsigned oelem = (unsigned)(((size_t)i * D.n1 + j) * D.n2) + (unsigned)kz;  // output element of this lane, step 0
+  const unsigned orow = (unsigned)(((size_t)i * D.n1 + j) * D.n2);  // first output element of this lane's row
 
-  for (int kb = 0; kb < D.n2; kb += KZ, oelem += KZ) {
-    const int kk = kb + kz;
-    const int k = min(kk, D.n2 - 1);
-    const bool live = live_row && kk < D.n2;
+  // One step of one lane, split in two so that the gathers of step s+1 are in flight while step s is blended:
+  //   issue(kb, P)  -- sampling position of voxel (i, j, kb + kz), the label gather and the four 8-byte gathers
+  //   finish(P)     -- weights, blend, epilogue, stores
+  struct Pend {
+    f2v p00, p10, p01, p11;
+    float x, y, z;
+    ST lab;
+  };
+  auto offset_of = [&](float x, float y, float z) {  // byte offset of the lower corner of the 2x2x2 neighbourhood
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+    return (unsigned)(base + __mul24(x0, sxs) + __mul24(y0, sy) + z0) * 4u;
+  };
+  auto issue = [&](int kb, Pend& P) {
+    const int k = min(kb + kz, D.n2 - 1);
     float px = pxb, py = pyb, pz = (float)k - D.cen[2];
-    if (has_field) {
+    if (has_field && ABL != 2) {
       const int4 c = s_tz[k];
       const float wl = __builtin_bit_cast(float, c.z), wh = __builtin_bit_cast(float, c.w);
       const float4 a = sf[c.x], b = sf[c.y];
@@ -127,30 +143,49 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
     float x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
     float y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
     float z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
+    if (ABL == 2) { x = (float)i + 0.25f; y = (float)j + 0.25f; z = (float)k * 0.98f + 0.3f; }
     x = __builtin_amdgcn_fmed3f(x, 0.f, hx) - m.mx;
     y = __builtin_amdgcn_fmed3f(y, 0.f, hy) - m.my;
     z = __builtin_amdgcn_fmed3f(z, 0.f, hz) - m.mz;
-    ST lab = 0;
+    P.x = x; P.y = y; P.z = z;
+    const bool mem = ABL != 1 || x == 1.2345e30f;  // ABL 1: never true, decided per lane at run time
+    P.lab = 0;
     if (HAS_NN) {
       const int xi = (int)rintf(x), yi = (int)rintf(y), zi = (int)rintf(z);  // round half to even; in range by construction
       const unsigned e = (unsigned)(base + __mul24(xi, sxs) + __mul24(yi, sy) + zi);
-      lab = lean_load_label<ST>(r_nn, e);  // stored after the blend: its latency overlaps the four gathers below
+      if (ABL != 1) P.lab = lean_load_label<ST>(r_nn, e);
+      else if (mem) P.lab = lean_load_label<ST>(r_nn, e);
+      else P.lab = (ST)(e & 7u);
     }
     if (HAS_LIN) {
-      const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f);  // x <= n-1 etc. hold by construction (clamped)
+      // unconditional: a voxel that samples outside the volume is clamped onto a face, its (unused) reads are in range and
+      // mostly hit the lines its neighbours fetch; a predicated gather would make the number of loads in flight unknown to
+      // the compiler, which then waits for ALL of them (vmcnt(0)) -- including the next step's -- before every blend
+      const unsigned o = offset_of(x, y, z);
+      if (ABL != 1 || mem) {
+        P.p00 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o, 0, 0));
+        P.p10 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)dxb, 0, 0));
+        P.p01 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)oyb, 0, 0));
+        P.p11 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)(dxb + oyb), 0, 0));
+      } else {
+        const float t = __builtin_bit_cast(float, (o & 0xFFFFu) | 0x3F800000u);
+        P.p00 = f2v{t, t + 1.f}; P.p10 = f2v{t + 2.f, t}; P.p01 = f2v{t, t + 3.f}; P.p11 = f2v{t + 1.f, t};
+      }
+    }
+  };
+  auto finish = [&](int kb, Pend& P) {
+    const int kk = kb + kz;
+    const bool live = live_row && kk < D.n2;
+    const unsigned oelem = orow + (unsigned)kk;
+    if (HAS_LIN) {
+      const float x = P.x, y = P.y, z = P.z;
+      const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f);
       const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-      const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
       const float bx = x - fx, by = y - fy, bz = z - fz;
       const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
-      const unsigned o = (unsigned)(base + __mul24(x0, sxs) + __mul24(y0, sy) + z0) * 4u;
-      f2v p00 = {0.f, 0.f}, p10 = {0.f, 0.f}, p01 = {0.f, 0.f}, p11 = {0.f, 0.f};
-      if (ok) {  // voxels that sample outside the volume (clamped onto a 0-face) need no data
-        p00 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o, 0, 0));
-        p10 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)dxb, 0, 0));
-        p01 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)oyb, 0, 0));
-        p11 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)(dxb + oyb), 0, 0));
-      }
-      if (ok && z0 >= D.n2 - 1) {  // rare (z exactly on the last column): single-element reads, upper neighbour unused
+      f2v p00 = P.p00, p10 = P.p10, p01 = P.p01, p11 = P.p11;
+      if (ok && (int)fz >= D.n2 - 1) {  // rare (z exactly on the last column): single-element reads, upper neighbour unused
+        const unsigned o = offset_of(x, y, z);
         p00.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o, 0, 0));
         p10.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)dxb, 0, 0));
         p01.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)oyb, 0, 0));
@@ -170,14 +205,30 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
         else v = 300.0f * powf(v / 300.0f, E.gamma);
       }
       if (has_bias) {
-        const int4 cb = s_bz[k];
+        const int4 cb = s_bz[min(kk, D.n2 - 1)];
         const float bval = fsg_mix(__builtin_bit_cast(float, cb.z), sb[cb.x], __builtin_bit_cast(float, cb.w), sb[cb.y]);
         v = v * (FAST ? __builtin_amdgcn_exp2f(bval * 1.4426950408889634f) : expf(bval));
       }
-      if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_olin, oelem * 4u, 0, 0);
+      if (live && (ABL != 1 || v == 1.2345e30f))
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_olin, oelem * 4u, 0, 0);
     }
-    if (HAS_NN && live) lean_store_label(r_onn, oelem, (DT)lab);
-    __syncthreads();  // the 16 waves stay on the same z slab: the brick's source block is what L1 holds
+    if (HAS_NN && live && (ABL != 1 || P.x == 1.2345e30f)) lean_store_label(r_onn, oelem, (DT)P.lab);
+  };
+
+  // the barrier only paces the 16 waves (same z slab -> the brick's source block is what L1 holds); nothing is
+  // exchanged through memory inside the loop, so no fence: loads of the next step stay in flight across it
+  Pend A, B;
+  issue(0, A);
+  for (int kb = 0; kb < D.n2; kb += 2 * KZ) {
+    const bool more1 = kb + KZ < D.n2;
+    if (more1) issue(kb + KZ, B);
+    finish(kb, A);
+    if (pace == 1) __builtin_amdgcn_s_barrier();
+    if (more1) {
+      if (kb + 2 * KZ < D.n2) issue(kb + 2 * KZ, A);
+      finish(kb + KZ, B);
+      if (pace) __builtin_amdgcn_s_barrier();
+    }
   }
 }
 
@@ -188,7 +239,17 @@ int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const fl
   constexpr int PI = WI, PJ = (16 / WI) * (64 / KZ);
   const dim3 grid((unsigned)(((D.n0 + PI - 1) / PI) * ((D.n1 + PJ - 1) / PJ))), block(1024);
 #define FSG_LEAN(L, N, F) \
-  hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E)
+  hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E, \
+                     g_lean_pace)
+  if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {  // diagnostic builds (tools/warp_ab.sh)
+    if (g_lean_ablate == 1)
+      hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 1>), grid, block, 0, st, D, mm6, src_lin, out_lin,
+                         src_nn, out_nn, E, g_lean_pace);
+    else
+      hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 2>), grid, block, 0, st, D, mm6, src_lin, out_lin,
+                         src_nn, out_nn, E, g_lean_pace);
+    FSG_RETURN_LAUNCH();
+  }
   if (src_lin && src_nn) { if (fast) FSG_LEAN(true, true, true); else FSG_LEAN(true, true, false); }
   else if (src_lin)      { if (fast) FSG_LEAN(true, false, true); else FSG_LEAN(true, false, false); }
   else                   { FSG_LEAN(false, true, true); }

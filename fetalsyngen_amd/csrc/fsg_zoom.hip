@@ -10,6 +10,7 @@
 // torch/numpy calls the reference uses, so sample positions are bit-identical; the kernel evaluates
 // x, then y, then z as w_lo*a + w_hi*b without FMA.
 #include "fsg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -44,15 +45,45 @@ struct EpiZ {
   int32_t* mm_out;
   const int32_t* mm_in;
   int norm_mode;
+  int mm_shards;  // 0 / 1: mm = {min, max}; S > 1: S slots of FSG_MM_SLOT_STRIDE ints, slot s = {min, max, ...} (fsg_hip.h)
 };
+
+// min / max keys of a (possibly sharded) pair.  Sharded: the two keys of a min/max pass are ONE address each, and a few
+// thousand workgroups ending with a gated atomic on them cost 15-25 us (profiles/r02_b_zoom_experiments.txt); with S slots
+// on separate 64-byte lines a workgroup updates slot blockIdx % S and the readers reduce the S slots (<= 64: one wave load).
+__device__ __forceinline__ void zoom_mm_update(const EpiZ& E, float lo, float hi) {
+  const int slot = E.mm_shards > 1 ? (int)(blockIdx.x % (unsigned)E.mm_shards) * FSG_MM_SLOT_STRIDE : 0;
+  fsg_atomic_min_key(&E.mm_out[slot], lo);
+  fsg_atomic_max_key(&E.mm_out[slot + 1], hi);
+}
+__device__ __forceinline__ void zoom_mm_read(const EpiZ& E, float& mn, float& mx) {
+  if (E.mm_shards > 1) {
+    const int lane = threadIdx.x & 63;
+    int kmin = 0x7FFFFFFF, kmax = (int)0x80000000;
+    if (lane < E.mm_shards) {
+      kmin = E.mm_in[lane * FSG_MM_SLOT_STRIDE];
+      kmax = E.mm_in[lane * FSG_MM_SLOT_STRIDE + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      kmin = min(kmin, __shfl_xor(kmin, o, FSG_WAVE));
+      kmax = max(kmax, __shfl_xor(kmax, o, FSG_WAVE));
+    }
+    mn = fsg_key2f(__builtin_amdgcn_readfirstlane(kmin));
+    mx = fsg_key2f(__builtin_amdgcn_readfirstlane(kmax));
+  } else {
+    mn = fsg_key2f(E.mm_in[0]);
+    mx = fsg_key2f(E.mm_in[1]);
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void zoom1_kernel(ZoomK Z, EpiZ E) {
   float lo = INFINITY, hi = -INFINITY;
   float inv_max = 0.f, mnq = 0.f, den = 1.f, mx = 1.f;
   if (EPI == EPI_NORM) {
-    mx = fsg_key2f(E.mm_in[1]);
-    const float mn = fsg_key2f(E.mm_in[0]);
+    float mn;
+    zoom_mm_read(E, mn, mx);
     mnq = mn / mx;         // min(y/max) == min(y)/max: IEEE division is monotone
     den = 1.0f - mnq;      // max(y/max) == max/max == 1
     (void)inv_max;
@@ -94,8 +125,7 @@ __global__ __launch_bounds__(256) void zoom1_kernel(ZoomK Z, EpiZ E) {
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-      fsg_atomic_min_key(&E.mm_out[0], lo);
-      fsg_atomic_max_key(&E.mm_out[1], hi);
+      zoom_mm_update(E, lo, hi);
     }
   }
 }
@@ -157,8 +187,9 @@ __global__ __launch_bounds__(256) void zoom1_rows_kernel(ZoomK Z, EpiZ E, int ro
   float lo = INFINITY, hi = -INFINITY;
   float mnq = 0.f, den = 1.f, mx = 1.f;
   if (EPI == EPI_NORM) {
-    mx = fsg_key2f(E.mm_in[1]);
-    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    float mn;
+    zoom_mm_read(E, mn, mx);
+    mnq = mn / mx;
     den = 1.0f - mnq;
   }
   const int nb = gridDim.x;
@@ -211,8 +242,7 @@ __global__ __launch_bounds__(256) void zoom1_rows_kernel(ZoomK Z, EpiZ E, int ro
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-      fsg_atomic_min_key(&E.mm_out[0], lo);
-      fsg_atomic_max_key(&E.mm_out[1], hi);
+      zoom_mm_update(E, lo, hi);
     }
   }
 }
@@ -229,8 +259,9 @@ __global__ __launch_bounds__(256, 8) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, 
   float lo = INFINITY, hi = -INFINITY;
   float mnq = 0.f, den = 1.f, mx = 1.f;
   if (EPI == EPI_NORM) {
-    mx = fsg_key2f(E.mm_in[1]);
-    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    float mn;
+    zoom_mm_read(E, mn, mx);
+    mnq = mn / mx;
     den = 1.0f - mnq;
   }
   const int nb = gridDim.x;
@@ -321,8 +352,7 @@ __global__ __launch_bounds__(256, 8) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, 
     __syncthreads();
     if (threadIdx.x == 0) {
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-      fsg_atomic_min_key(&E.mm_out[0], lo);
-      fsg_atomic_max_key(&E.mm_out[1], hi);
+      zoom_mm_update(E, lo, hi);
     }
   }
 }
@@ -357,8 +387,9 @@ __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY,
   float lo = INFINITY, hi = -INFINITY;
   float mnq = 0.f, den = 1.f, mx = 1.f;
   if (EPI == EPI_NORM) {
-    mx = fsg_key2f(E.mm_in[1]);
-    mnq = fsg_key2f(E.mm_in[0]) / mx;
+    float mn;
+    zoom_mm_read(E, mn, mx);
+    mnq = mn / mx;
     den = 1.0f - mnq;
   }
   // y taps of the tile and the window of source rows they reference
@@ -463,12 +494,197 @@ __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY,
     __syncthreads();
     if (tid == 0) {
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
-      fsg_atomic_min_key(&E.mm_out[0], lo);
-      fsg_atomic_max_key(&E.mm_out[1], hi);
+      zoom_mm_update(E, lo, hi);
     }
   }
 }
 
+// ---- slab variant (default for the passes without a noise draw: K9a min/max, K9b normalise, plain zoom) --------
+// The row kernels above are bound by a chain of dependent global round trips per output row (taps -> four source rows
+// -> LDS -> outputs, ~3.6 us per row and wave: profiles/r01_r_pmc_bench_kernels.json), the tile kernel by four LDS reads
+// and three blends per OUTPUT.  Here the three separable stages each run once per element they produce and only the
+// first touches global memory:
+//   1. x: as the tile kernel -- the window of source rows the tile's TY output rows reference, x-blended, coalesced,
+//      into LDS (one phase of global loads per workgroup);
+//   2. y: a wave blends two window rows into its private LDS row (sz elements, 2 LDS reads + 1 blend each);
+//   3. z: every lane emits four consecutive outputs of the row (2 LDS reads + 1 lerp each; the z taps of the lane's
+//      four outputs stay in registers when dz <= 256), one 16-byte store.
+// Blend order x -> y -> z with separate multiplies and adds: bit-identical to fsg_tab_interp<1> and to the other kernels.
+template <int EPI>
+__global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
+  // domain (checked by the launcher): sz <= 256 and dz <= 256 -- a lane owns source elements lane + 64 c (c < 4) in the
+  // y stage and outputs 4 lane .. 4 lane + 3 in the z stage, everything unrolled
+  extern __shared__ __attribute__((aligned(16))) float zt_smem[];
+  float* yr = zt_smem;              // [4 waves][sz] y-blended row of each wave
+  float* xs = yr + 4 * Z.sz;        // [window rows][sz] x-blended source rows
+  __shared__ fsg_tap tb[ZT_MAX_TY];
+  __shared__ int win[2];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tiles_y = (Z.dy + TY - 1) / TY;
+  const int ntiles = Z.dx * tiles_y;
+  const int nb = gridDim.x;
+  // workgroup -> contiguous run of tiles, runs dealt so that every XCD (blockIdx % 8) works on one slab of x planes.
+  // The min/max pass is launched with fewer workgroups than tiles: its two global keys are ONE address each, and 2 gated
+  // atomics per tile from 4 096 workgroups cost more than the whole evaluation (profiles/r02_b_zoom_experiments.txt).
+  const int wg = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int per = (ntiles + nb - 1) / nb;
+  float lo = INFINITY, hi = -INFINITY;
+  float mnq = 0.f, den = 1.f, mx = 1.f;
+  if (EPI == EPI_NORM) {
+    float mn;
+    zoom_mm_read(E, mn, mx);
+    mnq = mn / mx;
+    den = 1.0f - mnq;
+  }
+  // the z taps of this lane's four outputs: the same for every row of every tile
+  int zlo[4], zhi[4];
+  float zwl[4], zwh[4];
+  bool zok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = min(lane * 4 + u, Z.dz - 1);
+    const fsg_tap c = Z.tz[k];
+    zok[u] = c.lo >= 0 && lane * 4 + u < Z.dz;
+    zlo[u] = zok[u] ? c.lo : 0;
+    zhi[u] = zok[u] ? c.hi : 0;
+    zwl[u] = c.w_lo;
+    zwh[u] = c.w_hi;
+  }
+  const bool dst16 = (Z.dz & 3) == 0 && ((((uintptr_t)Z.dst) & 15) == 0);
+  const bool full = lane * 4 + 3 < Z.dz;
+  float* y = yr + wave * Z.sz;
+  for (int tile = wg * per; tile < min(ntiles, (wg + 1) * per); ++tile) {
+  const int i = tile / tiles_y, jt = tile - i * tiles_y;
+  const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
+  __syncthreads();  // previous tile's window and taps are no longer read
+  if (tid < 64) {
+    fsg_tap t = fsg_tap{-1, 0, 0.f, 0.f};
+    if (tid < nj) {
+      t = Z.ty[j0 + tid];
+      tb[tid] = t;
+    }
+    int smin = t.lo >= 0 ? t.lo : 0x7FFFFFFF, smax = t.lo >= 0 ? t.hi : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      smin = min(smin, __shfl_xor(smin, o, FSG_WAVE));
+      smax = max(smax, __shfl_xor(smax, o, FSG_WAVE));
+    }
+    if (tid == 0) { win[0] = smin; win[1] = smax; }
+  }
+  const fsg_tap a = zuniform_tap(Z.tx, i);
+  __syncthreads();
+  const int smin = win[0], nrows = win[1] - win[0] + 1;
+  const bool okx = a.lo >= 0 && nrows > 0;
+  const bool fits = nrows * Z.sz <= cap_floats;  // uniform; false only for tables that are not a plain zoom
+  if (okx && fits) {
+    const float* pa = Z.src + ((size_t)a.lo * Z.sy + smin) * Z.sz;
+    const float* pb = Z.src + ((size_t)a.hi * Z.sy + smin) * Z.sz;
+    const int tot = nrows * Z.sz;  // the window rows are contiguous in the source: one linear, coalesced sweep
+    for (int e = tid; e < tot; e += 256) xs[e] = fsg_mix(a.w_lo, pa[e], a.w_hi, pb[e]);
+  }
+  __syncthreads();
+  auto row_tap = [&](int jj) {
+    fsg_tap b = tb[jj];
+    b.lo = __builtin_amdgcn_readfirstlane(b.lo);
+    b.hi = __builtin_amdgcn_readfirstlane(b.hi);
+    b.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.w_lo)));
+    b.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b.w_hi)));
+    return b;
+  };
+  auto emit = [&](int jj, float (&v)[4]) {
+    const size_t o0 = ((size_t)i * Z.dy + j0 + jj) * Z.dz + (size_t)lane * 4;
+    if (EPI == EPI_NOISE_PHILOX) {
+      if (full && (o0 & 3) == 0) {
+        const float4 z = fsg_randn4(E.seed, E.stream_id, (uint64_t)(o0 >> 2));
+        v[0] += E.noise_std * z.x; v[1] += E.noise_std * z.y; v[2] += E.noise_std * z.z; v[3] += E.noise_std * z.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (lane * 4 + u < Z.dz) v[u] += E.noise_std * fsg_randn1(E.seed, E.stream_id, (uint64_t)(o0 + u));
+      }
+    } else if (EPI == EPI_NOISE_PTR) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane * 4 + u < Z.dz) v[u] += E.noise_std * E.noise[o0 + u];
+    }
+    if (EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = v[u] < 0.f ? 0.f : v[u];
+    } else if (EPI == EPI_NORM) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t = v[u] / mx;
+        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : (t - mnq) / den);
+        v[u] = t;
+      }
+    }
+    if (EPI == EPI_MINMAX) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane * 4 + u < Z.dz) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+    } else if (full && dst16) {
+      *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane * 4 + u < Z.dz) Z.dst[o0 + u] = v[u];
+    }
+  };
+  if (fits || !okx) {
+    for (int jj = wave; jj < nj; jj += 4) {
+      const fsg_tap b = row_tap(jj);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (okx && b.lo >= 0) {
+        const float* xl = xs + (b.lo - smin) * Z.sz;
+        const float* xh = xs + (b.hi - smin) * Z.sz;
+        float l4[4], h4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // all eight reads in flight before the first blend; indices clamped instead of predicated
+          const int zs = min(lane + 64 * c, Z.sz - 1);
+          l4[c] = xl[zs];
+          h4[c] = xh[zs];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int zs = lane + 64 * c;
+          if (zs < Z.sz) y[zs] = fsg_mix(b.w_lo, l4[c], b.w_hi, h4[c]);
+        }
+        zwave_sync();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float t = fsg_mix(zwl[u], y[zlo[u]], zwh[u], y[zhi[u]]);
+          v[u] = zok[u] ? t : 0.f;
+        }
+        zwave_sync();  // the wave's row is rewritten by its next iteration
+      }
+      emit(jj, v);
+    }
+  } else {  // window larger than the launch reserved (tables that are not a plain zoom): per-output evaluation
+    for (int jj = wave; jj < nj; jj += 4) {
+      const fsg_tap b = row_tap(jj);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (b.lo >= 0) {
+        for (int u = 0; u < 4; ++u)
+          if (zok[u]) v[u] = fsg_tab_interp<1>(Z.src, Z.sy, Z.sz, 0, a, b, fsg_tap{zlo[u], zhi[u], zwl[u], zwh[u]});
+      }
+      emit(jj, v);
+    }
+  }
+  }  // tiles of this workgroup
+  if (EPI == EPI_MINMAX) {
+    lo = fsg_wave_min(lo);
+    hi = fsg_wave_max(hi);
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    if (tid == 0 && E.norm_mode != 77) {
+      for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+      zoom_mm_update(E, lo, hi);
+    }
+  }
+}
+
+int g_zoom_mm_blocks = 1024;   // workgroups of the slab kernel's min/max pass (FSG_ZOOM_MM_BLOCKS overrides, tuning only)
 int g_zoom_ty = 16;            // output y rows per workgroup of zoom_tile_kernel
 int g_zoom_cap = 12288;        // LDS floats for the x-blended source window (48 KB)
 
@@ -486,7 +702,7 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   // measured at 256^3: the tile kernel wins where the Philox epilogue dominates (down-sampling + noise, K7: 27 vs 33 us
   // at m = 171, 42 vs 68 us at m = 256); the row kernels stay ahead for the up-sampling passes of K9 (30 vs 35-38 us)
   if ((EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR || (g_tuning_flags & FSG_TUNE_TILE_ZOOM)) &&
-      !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM))) {
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_SLAB_ZOOM))) {
     // window estimate for the tile kernel: TY rows advance sy/dy source rows each (+2 for the pair and rounding)
     int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;
@@ -496,6 +712,25 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
       const size_t lds = ((size_t)est + 4 * (size_t)Z.dz) * sizeof(float);  // window + z taps: as many workgroups per CU as fit
       hipLaunchKernelGGL(zoom_tile_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), lds, fsg_stream(stream), Z, E, TY,
                          (int)est);
+      FSG_RETURN_LAUNCH();
+    }
+  }
+  const bool noise_epi = EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR;
+  // measured at 256^3 (profiles/r02_b_zoom_experiments.txt): the slab kernel wins for the passes that store (K9b 28 vs 32.5 us);
+  // the min/max pass ends every workgroup with two gated atomics, which cost the slab kernel's 4 096 workgroups more than the
+  // row kernel's 2 048 (38 vs 31 us; 22 us with the atomics removed) whether or not the keys are sharded over slots
+  if (((!noise_epi && EPI != EPI_MINMAX) || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_TILE_ZOOM))) {
+    int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
+    if (TY > Z.dy) TY = Z.dy;
+    const long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
+    const long long total = est + 4LL * Z.sz;  // window + the four waves' rows
+    if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
+      const int tiles_y = (Z.dy + TY - 1) / TY;
+      int nblk = Z.dx * tiles_y;
+      if (EPI == EPI_MINMAX && E.mm_shards <= 1 && nblk > g_zoom_mm_blocks) nblk = g_zoom_mm_blocks;  // unsharded keys: fewer same-address atomics
+      hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3((unsigned)nblk), dim3(256), (size_t)total * sizeof(float),
+                         fsg_stream(stream), Z, E, TY, (int)est);
       FSG_RETURN_LAUNCH();
     }
   }
@@ -569,6 +804,9 @@ int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_ta
   ZoomK Z{src, sx, sy, sz, tx, ty, tz, nullptr, dx, dy, dz};
   EpiZ E{};
   E.mm_out = mm;
+  E.mm_shards = 1;
+  if (getenv("FSG_DIAG_NO_MM_ATOMICS")) E.norm_mode = 77;  // DIAGNOSTIC (timing only): results are wrong
+  if (const char* e = getenv("FSG_ZOOM_MM_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 65536) g_zoom_mm_blocks = v & ~7; }
   return launch1<EPI_MINMAX>(Z, E, stream);
 }
 
@@ -580,7 +818,31 @@ int fsg_zoom3d_normalise_f32(const float* src, int sx, int sy, int sz, const fsg
   if (!dst || !mm || src == dst || (mode != 0 && mode != 1)) return FSG_E_BADARG;
   ZoomK Z{src, sx, sy, sz, tx, ty, tz, dst, dx, dy, dz};
   EpiZ E{};
-  E.mm_in = mm; E.norm_mode = mode;
+  E.mm_in = mm; E.norm_mode = mode; E.mm_shards = 1;
+  return launch1<EPI_NORM>(Z, E, stream);
+}
+
+int fsg_zoom3d_minmax_sharded_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,
+                                  const fsg_tap* tz, int dx, int dy, int dz, int32_t* slots, int nslots, void* stream) {
+  int rc = check(src, sx, sy, sz, tx, ty, tz, dx, dy, dz);
+  if (rc) return rc;
+  if (!slots || nslots < 2 || nslots > 64) return FSG_E_BADARG;
+  ZoomK Z{src, sx, sy, sz, tx, ty, tz, nullptr, dx, dy, dz};
+  EpiZ E{};
+  E.mm_out = slots;
+  E.mm_shards = nslots;
+  return launch1<EPI_MINMAX>(Z, E, stream);
+}
+
+int fsg_zoom3d_normalise_sharded_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,
+                                     const fsg_tap* tz, float* dst, int dx, int dy, int dz, const int32_t* slots, int nslots,
+                                     int mode, void* stream) {
+  int rc = check(src, sx, sy, sz, tx, ty, tz, dx, dy, dz);
+  if (rc) return rc;
+  if (!dst || !slots || src == dst || (mode != 0 && mode != 1) || nslots < 2 || nslots > 64) return FSG_E_BADARG;
+  ZoomK Z{src, sx, sy, sz, tx, ty, tz, dst, dx, dy, dz};
+  EpiZ E{};
+  E.mm_in = slots; E.norm_mode = mode; E.mm_shards = nslots;
   return launch1<EPI_NORM>(Z, E, stream);
 }
 

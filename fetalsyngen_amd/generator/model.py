@@ -33,6 +33,11 @@ from .intensity.rand_gmm import ImageFromSeeds
 # [+inf x4 | -inf x4] as the order-preserving int32 keys of fsg_minmax_init (csrc/fsg_common.h: fsg_f2key)
 _MM8_INIT = np.array([0x7F800000] * 4 + [-2139095041] * 4, dtype=np.int32)
 _MM8_INIT.setflags(write=False)
+# K9's min / max keys sharded over 32 slots of 16 ints (include/fsg_hip.h: FSG_MM_SLOT_STRIDE), each {key(+inf), key(-inf), 0...}
+MM_NSLOTS, MM_SLOT_STRIDE = 32, 16
+_MM_SLOTS_INIT = np.zeros((MM_NSLOTS, MM_SLOT_STRIDE), dtype=np.int32)
+_MM_SLOTS_INIT[:, 0], _MM_SLOTS_INIT[:, 1] = 0x7F800000, -2139095041
+_MM_SLOTS_INIT.setflags(write=False)
 
 
 class FetalSynthGen:
@@ -128,7 +133,7 @@ class FetalSynthGen:
         return ws
 
     def _run_native(self, shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev, bias_tabs,
-                    rplan, rs_tabs, back_tabs, nplan, scale01, mm8_ptr=None):
+                    rplan, rs_tabs, back_tabs, nplan, scale01, mm8_ptr=None, mm_slots_ptr=None):
         """Fill a fsg_sample_plan and enqueue the whole sample with one call.  Returns (image, labels), or None
         when the configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
         import ctypes as C
@@ -209,6 +214,8 @@ class FetalSynthGen:
         else:
             p.mm8 = ws["mm8"].data_ptr()
         p.out = out.data_ptr()
+        if mm_slots_ptr is not None:
+            p.mm_slots, p.mm_nslots = mm_slots_ptr, MM_NSLOTS
         if self.blur_events is not None and rplan.active:  # (begin, end, n_passes) appended per sample
             lib = _lib.load()
             e0, e1 = lib.fsg_event_create(), lib.fsg_event_create()
@@ -358,6 +365,7 @@ class FetalSynthGen:
                 bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
                 back_tabs = K.device_tables_for(bt, dev)
             mm_off = arena.add(_MM8_INIT)  # the sample's min/max keys arrive initialised with its parameters
+            slots_off = None  # arena.add(_MM_SLOTS_INIT): sharded K9 keys measured no faster than the single pair (fsg_zoom.hip)
             gm_off = None
             if gmm_plan is not None:
                 gm_off = (arena.add(gmm_plan.mus.numpy()), arena.add(gmm_plan.sigmas.numpy()), gmm_plan.mus.numel())
@@ -378,7 +386,8 @@ class FetalSynthGen:
             if (self.native_pipeline and label_parts is not None and image is None and not has_art
                     and segmentation_u8 is None):
                 native = self._run_native(shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev,
-                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01, arena.ptr(mm_off))
+                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01, arena.ptr(mm_off),
+                                          mm_slots_ptr=(arena.ptr(slots_off) if slots_off is not None else None))
                 if native is not None:
                     return native[0], native[1], None, self._params(selected_seeds, seed_intensities, dplan, g, bplan,
                                                                     rplan, nplan, {})

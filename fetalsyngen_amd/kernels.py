@@ -288,12 +288,35 @@ def zoom_minmax(src, tabs: DeviceTables, mm=None) -> torch.Tensor:
     return mm
 
 
+MM_SLOT_STRIDE = 16  # include/fsg_hip.h: FSG_MM_SLOT_STRIDE
+
+
+def zoom_minmax_sharded(src, tabs: DeviceTables, nslots: int = 32) -> torch.Tensor:
+    """K9 pass A with the two keys sharded over `nslots` slots (nslots x 16 int32; what fsg_sample_run uses): a workgroup
+    updates slot (its index % nslots), `zoom_normalise` reduces the slots."""
+    sx, sy, sz = _zoom_args(src, tabs)
+    dx, dy, dz = tabs.lengths
+    init = np.zeros((nslots, MM_SLOT_STRIDE), dtype=np.int32)
+    init[:, 0], init[:, 1] = 0x7F800000, -2139095041  # key(+inf), key(-inf)
+    slots = torch.from_numpy(init).to(src.device)
+    tx, ty, tz = tabs.ptrs
+    _lib.check(_lib.load().fsg_zoom3d_minmax_sharded_f32(_p(src), sx, sy, sz, tx, ty, tz, dx, dy, dz, _p(slots), nslots,
+                                                         _stream(src)), "fsg_zoom3d_minmax_sharded_f32")
+    return slots
+
+
 def zoom_normalise(src, tabs: DeviceTables, mm, mode: int) -> torch.Tensor:
+    """`mm`: the two keys of `zoom_minmax`, or the (nslots, 16) slots of `zoom_minmax_sharded`."""
     sx, sy, sz = _zoom_args(src, tabs)
     _need_gpu(mm)
     dx, dy, dz = tabs.lengths
     dst = torch.empty((dx, dy, dz), dtype=F32, device=src.device)
     tx, ty, tz = tabs.ptrs
+    if mm.dim() == 2 and mm.shape[1] == MM_SLOT_STRIDE:
+        _lib.check(_lib.load().fsg_zoom3d_normalise_sharded_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz,
+                                                                _p(mm), int(mm.shape[0]), mode, _stream(src)),
+                   "fsg_zoom3d_normalise_sharded_f32")
+        return dst
     _lib.check(_lib.load().fsg_zoom3d_normalise_f32(_p(src), sx, sy, sz, tx, ty, tz, _p(dst), dx, dy, dz, _p(mm),
                                                     mode, _stream(src)), "fsg_zoom3d_normalise_f32")
     return dst

@@ -74,11 +74,12 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_NO_PREFETCH 8   /* row-wise zoom without the register-prefetch pipeline */
 #define FSG_TUNE_NO_PATCH 32     /* row kernel (4 waves, own rows) instead of the 16-wave lockstep patch kernel */
 #define FSG_TUNE_BUFFER_LOADS 64 /* opt in: patch kernel body on raw buffer loads (fewer instructions, slower in r01) */
-#define FSG_TUNE_ROW_ZOOM 256    /* resample + noise (K7): the row-per-wave kernels instead of the tile kernel */
+#define FSG_TUNE_ROW_ZOOM 256    /* every zoom through the row-per-wave kernels (r01 default for K9) */
 #define FSG_TUNE_TILE_ZOOM 512   /* every zoom through the tile kernel (default: only the noise epilogues) */
 #define FSG_TUNE_NO_BLUR_FUSE 1024 /* blur: y and z passes as two launches */
 #define FSG_TUNE_SA_DIRECT 128   /* slice-acquisition adjoint (interp_psf): direct global atomics, no LDS pre-summation */
 #define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
+#define FSG_TUNE_SLAB_ZOOM 8192 /* the slab zoom kernel also for the noise epilogues (default there: tile kernel) */
 #define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
@@ -142,6 +143,17 @@ int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_ta
 int fsg_zoom3d_normalise_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,
                              const fsg_tap* tz, float* dst, int dx, int dy, int dz, const int32_t* mm,
                              int mode, void* stream);
+
+/* Sharded form of the K9 pair (what fsg_sample_run uses): `slots` = nslots (2..64) slots of FSG_MM_SLOT_STRIDE int32 each,
+ * slot s = {min key, max key, unused...}, every slot initialised by the caller to {key(+inf), key(-inf)} (the values
+ * fsg_minmax_init writes).  The min/max pass updates slot (workgroup index % nslots); the normalise pass reduces the
+ * slots itself.  Same results as the unsharded pair; the keys no longer sit on one contended address. */
+#define FSG_MM_SLOT_STRIDE 16
+int fsg_zoom3d_minmax_sharded_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,
+                                  const fsg_tap* tz, int dx, int dy, int dz, int32_t* slots, int nslots, void* stream);
+int fsg_zoom3d_normalise_sharded_f32(const float* src, int sx, int sy, int sz, const fsg_tap* tx, const fsg_tap* ty,
+                                     const fsg_tap* tz, float* dst, int dx, int dy, int dz, const int32_t* slots, int nslots,
+                                     int mode, void* stream);
 
 /* ---- K2/K3: deformation coordinates (affine_nonrigid.py:64-84, :299-366) ----------------------- */
 /* Reset six int32 keys to (+inf,+inf,+inf,-inf,-inf,-inf) / two keys to (+inf,-inf). */
@@ -412,6 +424,9 @@ typedef struct fsg_sample_plan {
   float* out;                    /* shape[] floats                                                            */
   void* ev_blur_begin;           /* optional hipEvent_t pair recorded around the blur passes (fsg_event_*)     */
   void* ev_blur_end;
+  int32_t* mm_slots;             /* optional: mm_nslots initialised slots (see fsg_zoom3d_minmax_sharded_f32) for the min / max
+                                    of the zoom-back; the [0,1] scaling then reads them instead of mm8[3..4] */
+  int32_t mm_nslots;
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
 

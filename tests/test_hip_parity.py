@@ -250,9 +250,10 @@ def test_blur_fast_paths_match_oracle_and_properties(K):
 
 
 def test_zoom_tile_kernel_equals_row_kernels(K):
-    """The tile kernel (x-blended source rows staged once per workgroup, four outputs and one Philox block per thread) against
-    the row-per-wave kernels, for every epilogue, up- and down-sampling, ragged sizes: bit-identical (same x -> y -> z
-    operation order, same Philox counter -> element mapping)."""
+    """The tile kernel (x-blended source rows staged once per workgroup, four outputs and one Philox block per thread) and the
+    slab kernel (x, y, z stages through LDS, four consecutive outputs per lane) against the row-per-wave kernels, for every
+    epilogue, up- and down-sampling, ragged sizes: bit-identical (same x -> y -> z operation order, same Philox counter ->
+    element mapping)."""
     from fetalsyngen_amd import _lib
     from fetalsyngen_amd import tables as T
 
@@ -266,10 +267,10 @@ def test_zoom_tile_kernel_equals_row_kernels(K):
         bt, _ = T.zoom_tables(new, 1 / np.asarray(fac))
         zt = K.DeviceTables(bt, DEV)
         res = {}
-        for flag in (256, 512):  # FSG_TUNE_ROW_ZOOM, FSG_TUNE_TILE_ZOOM
+        for flag in (256, 512, 8192, 0):  # FSG_TUNE_ROW_ZOOM, FSG_TUNE_TILE_ZOOM, FSG_TUNE_SLAB_ZOOM, defaults
             prev = lib.fsg_set_tuning(flag)
             try:
-                for ty in ((16,) if flag == 256 else (1, 5, 16, 32)):
+                for ty in ((16,) if flag in (256, 0) else (1, 5, 16, 32)):
                     lib.fsg_zoom_set_tuning(ty, 12288)
                     low = K.resample_noise(x, rt, noise_std=9.0, seed=11, stream_id=2)
                     z = K.randn(tuple(new), 5, 6, DEV)
@@ -277,6 +278,13 @@ def test_zoom_tile_kernel_equals_row_kernels(K):
                     plain = K.zoom3d(x, rt)
                     mm = K.zoom_minmax(low, zt)
                     up = [K.zoom_normalise(low, zt, mm, mode) for mode in (0, 1)]
+                    # the same pair with the keys sharded over slots (what fsg_sample_run uses)
+                    for nslots in (2, 32, 64):
+                        slots = K.zoom_minmax_sharded(low, zt, nslots)
+                        sk = host(slots)
+                        assert sk[:, 0].min() == int(mm[0]) and sk[:, 1].max() == int(mm[1]) and not sk[:, 2:].any()
+                        for mode in (0, 1):
+                            assert torch.equal(K.zoom_normalise(low, zt, slots, mode), up[mode]), (shape, m, flag, nslots)
                     res[(flag, ty)] = [low, low2, plain, mm] + up
             finally:
                 lib.fsg_set_tuning(prev)

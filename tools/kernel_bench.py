@@ -101,5 +101,8 @@ zt = K.DeviceTables(bt2, dev)
 mm = K.zoom_minmax(low, zt)
 timeit(f"zoom_minmax_m{new[0]}", lambda: K.zoom_minmax(low, zt), 4 * M)
 timeit(f"zoom_normalise_m{new[0]}", lambda: K.zoom_normalise(low, zt, mm, 1), 4 * M + 4 * N)
+slots = K.zoom_minmax_sharded(low, zt)
+timeit(f"zoom_sharded_minmax_m{new[0]}", lambda: K.zoom_minmax_sharded(low, zt), 4 * M)
+timeit(f"zoom_sharded_normalise_m{new[0]}", lambda: K.zoom_normalise(low, zt, slots, 1), 4 * M + 4 * N)
 timeit("reduce_minmax", lambda: K.reduce_minmax(img), 4 * N)
 timeit("scale", lambda: K.scale(img, K.reduce_minmax(img), 1), 12 * N)
