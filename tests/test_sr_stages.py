@@ -45,6 +45,15 @@ def host(x):
     return x.detach().cpu().numpy()
 
 
+def _report(tag, d, levels):
+    """FSG_TEST_REPORT=1: print how far a result is from its golden (used to set the tolerances below)."""
+    import os
+
+    if os.environ.get("FSG_TEST_REPORT"):
+        print(f"[report] {tag}: max {float(d.max()):.3e}, " + ", ".join(f"frac>{l:g} {float((d > l).mean()):.2e}" for l in levels)
+              + f", n>{levels[0]:g} {int((d > levels[0]).sum())} of {d.size}")
+
+
 def next_draws():
     return np.array([np.random.rand(), float(torch.rand(1))])
 
@@ -134,7 +143,8 @@ def test_scan_intermediates_vs_reference(env, golden):
     np.testing.assert_allclose(host(ds["psf_rec"]), g["scan_psf_rec"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(host(ds["stacks_no_psf"])[:, 0], g["scan_stacks_no_psf"], atol=1e-5)
     d = np.abs(host(ds["stacks"])[:, 0] - g["scan_stacks"])
-    assert (d > 2e-5).mean() < 1e-3 and d.max() < 1e-2, (float((d > 2e-5).mean()), float(d.max()))
+    _report("scan_stacks", d, (2e-5, 2e-4))
+    assert d.max() < 1e-5, float(d.max())  # measured 1.1e-6 (MI355X box, r02): the acquisition has no discontinuous decision left
     assert np.array_equal(next_draws(), g["scan_next"])
 
 
@@ -158,10 +168,16 @@ def test_simulate_motion_vs_reference(env, golden, case):
             assert np.array_equal(np.asarray(v, dtype=ref.dtype), ref), k
     assert np.array_equal(next_draws(), g[f"{case}_next"])
     assert tuple(y.shape) == (32, 32, 32)
-    # nearest-voxel scatter: an ulp in a transform (libm differences between hosts) moves a sample that sits on a
-    # voxel boundary to the neighbouring voxel -- a handful of voxels may differ by more than the tolerance
+    # The scan agrees with the reference to 1e-6 (test above); what remains comes from the reconstruction, whose
+    # nearest-voxel scatter (round-half-even), 1e-2 weight threshold and equalisation are discontinuous: a sample on a voxel
+    # boundary lands one voxel over when fp32 sums are ordered differently.  Measured on the MI355X box (r02): 7 / 72 / 15
+    # of 32 768 voxels beyond 2e-5, 4 / 0 / 5 beyond 2e-4, max 2.5e-3.  The bounds below are ~3x those counts; that each
+    # outlier IS such a flip is the explanation, not something this test proves (it would need the reference's
+    # intermediate sample positions, which the golden file does not hold).
     d = np.abs(host(y) - g[f"{case}_out"])
-    assert (d > 2e-4).mean() < 1e-3 and d.max() < 1e-2, (float((d > 2e-4).mean()), float(d.max()))
+    _report(f"simulate_motion[{case}]", d, (2e-5, 2e-4))
+    assert int((d > 2e-5).sum()) <= 220 and int((d > 2e-4).sum()) <= 16 and d.max() < 8e-3, (
+        int((d > 2e-5).sum()), int((d > 2e-4).sum()), float(d.max()))
 
 
 # ---- BlurCortex / StructNoise -----------------------------------------------------------------------------------
@@ -288,7 +304,11 @@ def test_generator_with_all_sr_stages_vs_reference(env, golden, case, seed):
     assert np.array_equal(next_draws(), g[f"{case}_next"])
     assert np.array_equal(host(seg_out).astype(np.uint8), g[f"{case}_seg"])
     d = np.abs(host(y) - g[f"{case}_out"])
-    assert (d > 5e-4).mean() < 2e-3 and d.max() < 5e-2, (float((d > 5e-4).mean()), float(d.max()))
+    _report(f"e2e_art[{case}]", d, (2e-5, 5e-4))
+    # measured (MI355X box, r02): 79 / 31 of 110 592 voxels beyond 2e-5, 11 / 6 beyond 5e-4, max 1.2e-2 (see the note in
+    # test_simulate_motion_vs_reference: discontinuous decisions of the reconstruction, then spread by the later stages)
+    assert int((d > 2e-5).sum()) <= 250 and int((d > 5e-4).sum()) <= 32 and d.max() < 4e-2, (
+        int((d > 2e-5).sum()), int((d > 5e-4).sum()), float(d.max()))
 
 
 def test_scan_and_recon_on_a_coarser_grid_vs_reference(env, golden):
