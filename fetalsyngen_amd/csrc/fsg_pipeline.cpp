@@ -148,6 +148,16 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   return 0;
 }
 
+// B samples with one native call (B volumes per call for DataLoader-style consumers).  Plan b is enqueued on
+// streams[b % nstreams]; with nstreams > 1 consecutive samples overlap their kernel tails (the caller has ordered those
+// streams behind the upload of the plans' parameters and joins them afterwards).  Results are those of B fsg_sample_run
+// calls: the kernels, their arguments and their order per sample are the same.
+extern "C" int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams) {
+  if (!plans || nplans < 0 || !streams || nstreams < 1) return FSG_E_BADARG;
+  for (int b = 0; b < nplans; ++b) FSG_TRY(fsg_sample_run(&plans[b], streams[b % nstreams]));
+  return 0;
+}
+
 // Thin hipEvent helpers so a ctypes caller can time sections of fsg_sample_run on the launch stream.
 extern "C" void* fsg_event_create(void) {
   hipEvent_t e = nullptr;

@@ -57,9 +57,40 @@ __global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, co
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e];
 }
 
+// fp32 -> fp16 (round to nearest even), 8 elements per thread where alignment allows: the optional half-precision image
+// of the output side (a [0,1] image keeps 11 significant bits)
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ x, size_t n, _Float16* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const size_t n8 = n >> 3;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    h8* o8 = reinterpret_cast<h8*>(out);
+    for (size_t g = e0; g < n8; g += stride) {
+      const float4 a = x4[2 * g], b = x4[2 * g + 1];
+      h8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+      o8[g] = h;
+    }
+    for (size_t g = (n8 << 3) + e0; g < n; g += stride) out[g] = (_Float16)x[g];
+  } else {
+    for (size_t g = e0; g < n; g += stride) out[g] = (_Float16)x[g];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fsg_cast_f32_to_f16(const float* x, size_t n, void* out_f16, void* stream) {
+  if (n == 0) return 0;
+  if (!x || !out_f16) return FSG_E_BADARG;
+  size_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, fsg_stream(stream), x, n, (_Float16*)out_f16);
+  FSG_RETURN_LAUNCH();
+}
 
 int fsg_copy_bytes(void* dst, const void* src, size_t nbytes, void* stream) {
   if (!dst || !src || nbytes == 0 || (nbytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return FSG_E_BADARG;

@@ -211,6 +211,33 @@ class FetalSynthDataset(FetalDataset):
         data_out = {"image": gen_output.unsqueeze(0), "label": label.unsqueeze(0), "name": name}
         return data_out, generation_params
 
+    def sample_batch(self, indices, genparams_list=None, streams: int = 1):
+        """B subjects with one `FetalSynthGen.sample_batch` call (seeds-based generation, cached label volumes): what a
+        DataLoader with batch_size=B would collate from B `__getitem__` calls (reference data/datasets.py:310-325) --
+        {"image": (B,1,H,W,D) float32 in [0,1], "label": (B,1,H,W,D) int64, "name": [B]} on the CPU, or on the device with
+        uint8 labels when `return_device` -- and the list of B generation_params.  Same draws, same values as B
+        consecutive `sample` calls."""
+        if self.load_image or self.image_as_intensity or self.seed_path is None or not self.cache_on_device:
+            raise ValueError("sample_batch serves the seeds-based path with device-cached label volumes "
+                             "(load_image=False, image_as_intensity=False, cache_on_device=True)")
+        indices = [int(i) for i in indices]
+        names = [self._sub_ses_idx(i) for i in indices]
+        t0 = time.time()
+        items = [(None, self._segmentation(i), self._seeds_for(n)) for i, n in zip(indices, names)]
+        out, seg, _imgs, params = self.generator.sample_batch(items, genparams_list, scale01=True, streams=streams)
+        if not torch.is_tensor(out):
+            raise ValueError("sample_batch needs subjects of one shape")
+        if self.return_device:
+            image, label = out.unsqueeze(1), seg.to(torch.uint8).unsqueeze(1)
+        else:
+            image, label = out.cpu().unsqueeze(1), seg.cpu().long().unsqueeze(1)
+        dt = time.time() - t0
+        gps = []
+        for i, p_ in zip(indices, params):
+            gps.append({"idx": i, "img_paths": str(self.img_paths[i]), "segm_paths": str(self.img_paths[i]),
+                        "seeds": str(self.seed_path), **p_, "generation_time": dt / max(len(indices), 1)})
+        return {"image": image, "label": label, "name": names}, gps
+
     def __getitem__(self, idx) -> dict:
         data_out, generation_params = self.sample(idx)
         self.generation_params = generation_params

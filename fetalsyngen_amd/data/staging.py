@@ -20,21 +20,27 @@ class HostStager:
     slots stay untouched behind them, so the views `collect` hands out remain valid until `keep` further
     samples have been collected (default 2: the sample just yielded and the one before it)."""
 
-    def __init__(self, shape, device, depth: int = 3, label_dtype=torch.int64, keep: int = 2):
+    def __init__(self, shape, device, depth: int = 3, label_dtype=torch.int64, keep: int = 2, batch: int | None = None,
+                 image_dtype=torch.float32):
+        """shape: (H,W,D) of one volume.  batch=None: slots hold one sample, (1,H,W,D) as `FetalSynthDataset.__getitem__`
+        returns it; batch=B: slots hold B samples, (B,1,H,W,D) as a collated DataLoader batch, moved with ONE copy per
+        tensor.  image_dtype=torch.float16 halves the image bytes (conversion by fsg_cast_f32_to_f16 on the device)."""
         self.device = torch.device(device)
         self.depth = depth
         self.keep = max(int(keep), 1)
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        full = (1, *shape) if batch is None else (int(batch), 1, *shape)
         self.slots = []
         for _ in range(depth + self.keep):
             self.slots.append({
-                "image": torch.empty((1, *shape), dtype=torch.float32, pin_memory=True),
-                "label": torch.empty((1, *shape), dtype=label_dtype, pin_memory=True),
+                "image": torch.empty(full, dtype=image_dtype, pin_memory=True),
+                "label": torch.empty(full, dtype=label_dtype, pin_memory=True),
                 "event": torch.cuda.Event(),
                 "busy": False,
             })
         self._next = 0
         self.label_dtype = label_dtype
+        self.image_dtype = image_dtype
 
     def submit(self, image_dev: torch.Tensor, label_dev: torch.Tensor) -> int:
         """Enqueue the D2H copies of one sample; returns a ticket for `collect`."""
@@ -46,6 +52,12 @@ class HostStager:
         # the dtype conversion runs on the PRODUCING stream (the caching allocator then knows who reads
         # `label_dev`); the copy stream only ever touches tensors that carry a record_stream mark
         lab = label_dev if label_dev.dtype == self.label_dtype else label_dev.to(self.label_dtype)
+        if image_dev.dtype != self.image_dtype:
+            if self.image_dtype != torch.float16:
+                raise TypeError("HostStager image_dtype must be torch.float32 or torch.float16")
+            from .. import kernels as K
+
+            image_dev = K.cast_f16(image_dev)
         produced = torch.cuda.Event()
         produced.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.copy_stream):
@@ -81,10 +93,16 @@ class PrefetchingStream:
     collating B samples needs keep >= B, or `.clone()`)."""
 
     def __init__(self, dataset, indices, base_seed: int = 0, depth: int = 3, to_host: bool = True,
-                 label_dtype=torch.int64, keep: int = 2):
+                 label_dtype=torch.int64, keep: int = 2, batch_size: int | None = None, image_dtype=torch.float32,
+                 batch_streams: int = 1):
+        """batch_size=B: B consecutive indices are generated by one `FetalSynthGen.sample_batch` call (one parameter
+        upload, one native call, `batch_streams` HIP streams) and yielded as one collated item -- image (B,1,H,W,D),
+        label (B,1,H,W,D), name: list of B -- moved to the host with one copy per tensor.  Sample i is seeded with
+        (base_seed, i) whatever the batch size, so the stream of samples does not depend on it."""
         self.ds, self.indices, self.base_seed, self.depth, self.to_host = dataset, list(indices), base_seed, depth, to_host
         self.label_dtype = label_dtype
         self.keep = keep
+        self.batch_size, self.image_dtype, self.batch_streams = batch_size, image_dtype, batch_streams
         self._stager = None
 
     def __len__(self):
@@ -99,7 +117,54 @@ class PrefetchingStream:
         out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True)
         return out, seg, name
 
+    def _produce_batch(self, idxs):
+        """B samples, each seeded with its own (base_seed, i) key: the generator's global RNGs are re-seeded between the
+        samples' host draws, so `sample_batch` cannot be handed the whole list at once -- the draws of sample b are made
+        by `_prepare` right after its seeding, through the items iterator."""
+        ds, gen = self.ds, self.ds.generator
+        names = []
+
+        def items():
+            for i in idxs:
+                sharding.seed_for_sample(self.base_seed, i)
+                idx = i % len(ds)
+                name = ds._sub_ses_idx(idx)
+                names.append(name)
+                yield (None, ds._segmentation(idx), ds._seeds_for(name))
+
+        out, seg, _imgs, _params = gen.sample_batch(items(), scale01=True, streams=self.batch_streams, lazy_items=len(idxs))
+        return out, seg, names
+
+    def _iter_batches(self):
+        B = int(self.batch_size)
+        chunks = [self.indices[s:s + B] for s in range(0, len(self.indices), B)]
+        if not self.to_host:
+            for ch in chunks:
+                out, seg, names = self._produce_batch(ch)
+                yield {"image": out.unsqueeze(1), "label": seg.to(torch.uint8).unsqueeze(1), "name": names}
+            return
+        pending = deque()
+        stagers = {}  # a ragged last batch gets its own (smaller) ring
+        for ch in chunks:
+            out, seg, names = self._produce_batch(ch)
+            st = stagers.get(len(ch))
+            if st is None:
+                st = stagers[len(ch)] = HostStager(tuple(out.shape[1:]), out.device, self.depth, self.label_dtype, self.keep,
+                                                   batch=len(ch), image_dtype=self.image_dtype)
+            if len(pending) >= self.depth:
+                s_, t_, n_ = pending.popleft()
+                img, lab = s_.collect(t_)
+                yield {"image": img, "label": lab, "name": n_}
+            pending.append((st, st.submit(out.unsqueeze(1), seg.unsqueeze(1)), names))
+        while pending:
+            s_, t_, n_ = pending.popleft()
+            img, lab = s_.collect(t_)
+            yield {"image": img, "label": lab, "name": n_}
+
     def __iter__(self):
+        if self.batch_size:
+            yield from self._iter_batches()
+            return
         if not self.to_host:
             for i in self.indices:
                 out, seg, name = self._produce(i)
@@ -109,7 +174,8 @@ class PrefetchingStream:
         for i in self.indices:
             out, seg, name = self._produce(i)
             if self._stager is None:
-                self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype, self.keep)
+                self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype, self.keep,
+                                          image_dtype=self.image_dtype)
             if len(pending) >= self.depth:
                 t, n = pending.popleft()
                 img, lab = self._stager.collect(t)

@@ -40,6 +40,10 @@ _MM_SLOTS_INIT[:, 0], _MM_SLOTS_INIT[:, 1] = 0x7F800000, -2139095041
 _MM_SLOTS_INIT.setflags(write=False)
 
 
+class _Ctx:
+    """One prepared sample: its plans, arena offsets and (after _resolve) device views."""
+
+
 class FetalSynthGen:
     def __init__(
         self,
@@ -132,68 +136,43 @@ class FetalSynthGen:
             ws["rows"] = torch.empty(shape[0] * shape[1] * ws["stride"], dtype=torch.float32, device=dev)
         return ws
 
-    def _run_native(self, shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev, bias_tabs,
-                    rplan, rs_tabs, back_tabs, nplan, scale01, mm8_ptr=None, mm_slots_ptr=None):
-        """Fill a fsg_sample_plan and enqueue the whole sample with one call.  Returns (image, labels), or None
-        when the configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
+    def _fill_native_plan(self, p, c, scale01, ws, out, seg_out):
+        """Fill the fsg_sample_plan `p` of prepared sample `c` (see _prepare / _resolve).  `out` / `seg_out`: where the
+        image and the deformed labels go (seg_out is ignored when there is no deformation).  Returns False when the
+        configuration is outside the fused kernels' domain (blur radius beyond the plan's tap capacity)."""
         import ctypes as C
 
         from .. import _lib
 
         dev = torch.device(self.device)
-        seg = segmentation.to(dev)
-        if seg.dtype != torch.float32:
-            seg = seg.float()
-        seg = seg.contiguous()
-        # the C side only receives pointers: every operand shape / dtype / device is checked here, because a
-        # mismatched volume would make the fused kernels gather outside a smaller buffer
-        shape = tuple(int(v) for v in shape)
-        if tuple(seg.shape) != shape:
-            raise ValueError(f"segmentation shape {tuple(seg.shape)} differs from the seed volumes' shape {shape}")
-        if not 1 <= len(label_parts) <= 4:
-            raise ValueError(f"{len(label_parts)} seed label volumes: the fused path takes 1..4")
-        for q, part in enumerate(label_parts):
-            off_dev = part.device.type != dev.type or (dev.index is not None and part.device.index != dev.index)
-            if tuple(part.shape) != shape or part.dtype != torch.uint8 or not part.is_contiguous() or off_dev:
-                raise ValueError(
-                    f"seed label volume {q}: expected a contiguous uint8 tensor of shape {shape} on {dev}, got "
-                    f"{part.dtype} {tuple(part.shape)} on {part.device} (contiguous={part.is_contiguous()})")
-        if mus.numel() != sigmas.numel() or not 1 <= mus.numel() <= 256:
-            raise ValueError(f"mus / sigmas tables of {mus.numel()} / {sigmas.numel()} entries (need equal, 1..256)")
-        f2 = int(spec.c.field_dims[2]) if spec is not None else 0
-        b2 = int(bias_dev.shape[2]) if bias_dev is not None else 0
-        ws = self._workspace(shape, 3 * f2 + b2 if spec is not None else 0)
-        p = _lib.SamplePlan()
+        shape, seg, spec, rplan, nplan = c.shape, c.seg, c.spec, c.rplan, c.nplan
         p.shape[:] = shape
-        for q, part in enumerate(label_parts):
+        for q, part in enumerate(c.label_parts):
             p.label_parts[q] = part.data_ptr()
-        p.mus, p.sigmas, p.ntab = mus.data_ptr(), sigmas.data_ptr(), int(mus.numel())
-        f = gmm_plan.field
-        keep = [seg]
+        p.mus, p.sigmas, p.ntab = c.mus.data_ptr(), c.sigmas.data_ptr(), int(c.mus.numel())
+        f = c.gmm_plan.field
         if f.host is not None:
             z = f.device_tensor(dev)
-            keep.append(z)
+            c.keep.append(z)
             p.gmm_noise = z.data_ptr()
         else:
             p.gmm_seed, p.gmm_stream = f.seed, f.stream_id
-        out = torch.empty(shape, dtype=torch.float32, device=dev)
-        seg_out = seg
         if spec is not None:
             p.deform_active = 1
             p.deform = spec.c
-            seg_out = torch.empty_like(seg)
             p.seg_in, p.seg_out = seg.data_ptr(), seg_out.data_ptr()
-        p.epi = K._epilogue(gam, bias_dev, bias_tabs, shape)
+        p.epi = K._epilogue(c.gam, c.bias_dev, c.bias_tabs, shape)
+        c.keep.append(p.epi)
         if rplan.active:
             p.resample_active = 1
             p.low_shape[:] = rplan.new_size
-            for a_, (t1, t2) in enumerate(zip(rs_tabs.ptrs, back_tabs.ptrs)):
+            for a_, (t1, t2) in enumerate(zip(c.rs_tabs.ptrs, c.back_tabs.ptrs)):
                 p.rs_tab[a_], p.back_tab[a_] = t1.value, t2.value
             for a_ in range(3):
                 if rplan.stds[a_] > 0:
                     taps = T.gaussian_taps(float(rplan.stds[a_]))
                     if len(taps) > 129:
-                        return None
+                        return False
                     p.blur_ntaps[a_] = len(taps)
                     C.memmove(p.blur_taps[a_], taps.ctypes.data, taps.nbytes)
         if nplan.active:
@@ -201,7 +180,7 @@ class FetalSynthGen:
             p.noise_std = nplan.std32
             if nf.host is not None:
                 zn = nf.device_tensor(dev)
-                keep.append(zn)
+                c.keep.append(zn)
                 p.noise_mode, p.noise = 1, zn.data_ptr()
             else:
                 p.noise_mode, p.noise_seed, p.noise_stream = 2, nf.seed, nf.stream_id
@@ -209,14 +188,59 @@ class FetalSynthGen:
         p.ws0, p.ws1, p.ws_low = ws["ws0"].data_ptr(), ws["ws1"].data_ptr(), ws["low"].data_ptr()
         if ws["rows"] is not None:
             p.ws_rows, p.row_stride = ws["rows"].data_ptr(), ws["stride"]
-        if mm8_ptr is not None:
-            p.mm8, p.mm8_preset = mm8_ptr, 1
-        else:
-            p.mm8 = ws["mm8"].data_ptr()
+        p.mm8, p.mm8_preset = c.arena.ptr(c.mm_off), 1
         p.out = out.data_ptr()
-        if mm_slots_ptr is not None:
-            p.mm_slots, p.mm_nslots = mm_slots_ptr, MM_NSLOTS
-        if self.blur_events is not None and rplan.active:  # (begin, end, n_passes) appended per sample
+        return True
+
+    def _native_ok(self, c) -> bool:
+        return (self.native_pipeline and c.label_parts is not None and c.image is None and not c.has_art
+                and c.segmentation_u8 is None)
+
+    def _native_operands(self, c):
+        """Shape / dtype / device checks of everything the C side only sees as pointers (a mismatched volume would make
+        the fused kernels gather outside a smaller buffer), and the float32 device segmentation."""
+        dev = torch.device(self.device)
+        seg = c.segmentation.to(dev)
+        if seg.dtype != torch.float32:
+            seg = seg.float()
+        seg = seg.contiguous()
+        shape = tuple(int(v) for v in c.shape)
+        if tuple(seg.shape) != shape:
+            raise ValueError(f"segmentation shape {tuple(seg.shape)} differs from the seed volumes' shape {shape}")
+        if not 1 <= len(c.label_parts) <= 4:
+            raise ValueError(f"{len(c.label_parts)} seed label volumes: the fused path takes 1..4")
+        for q, part in enumerate(c.label_parts):
+            off_dev = part.device.type != dev.type or (dev.index is not None and part.device.index != dev.index)
+            if tuple(part.shape) != shape or part.dtype != torch.uint8 or not part.is_contiguous() or off_dev:
+                raise ValueError(
+                    f"seed label volume {q}: expected a contiguous uint8 tensor of shape {shape} on {dev}, got "
+                    f"{part.dtype} {tuple(part.shape)} on {part.device} (contiguous={part.is_contiguous()})")
+        if c.mus.numel() != c.sigmas.numel() or not 1 <= c.mus.numel() <= 256:
+            raise ValueError(f"mus / sigmas tables of {c.mus.numel()} / {c.sigmas.numel()} entries (need equal, 1..256)")
+        c.shape, c.seg = shape, seg
+        c.keep.append(seg)
+
+    def _rows_needed(self, c) -> int:
+        f2 = int(c.spec.c.field_dims[2]) if c.spec is not None else 0
+        b2 = int(c.bias_dev.shape[2]) if c.bias_dev is not None else 0
+        return 3 * f2 + b2 if c.spec is not None else 0
+
+    def _run_native(self, c, scale01):
+        """Enqueue prepared sample `c` with one fsg_sample_run call.  Returns (image, labels), or None when the
+        configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
+        import ctypes as C
+
+        from .. import _lib
+
+        dev = torch.device(self.device)
+        self._native_operands(c)
+        ws = self._workspace(c.shape, self._rows_needed(c))
+        out = torch.empty(c.shape, dtype=torch.float32, device=dev)
+        seg_out = torch.empty_like(c.seg) if c.spec is not None else c.seg
+        p = _lib.SamplePlan()
+        if not self._fill_native_plan(p, c, scale01, ws, out, seg_out):
+            return None
+        if self.blur_events is not None and c.rplan.active:  # (begin, end, n_passes) appended per sample
             lib = _lib.load()
             e0, e1 = lib.fsg_event_create(), lib.fsg_event_create()
             p.ev_blur_begin, p.ev_blur_end = e0, e1
@@ -326,79 +350,191 @@ class FetalSynthGen:
             gmm_plan = self.intensity_generator.plan_intensities(tuple(shape), genparams.get("seed_intensities", {}))
             return (m2s, gmm_plan) + self._draw_plans(tuple(shape), genparams)
 
-    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
+    # A sample goes through three host phases so that B samples can share one parameter upload and one native call:
+    #   _prepare : every random draw, in the reference's order, and the small arrays added to the arena   (no device work)
+    #   arena.upload
+    #   _resolve : device views of the uploaded arrays
+    # then either one fsg_sample_run / fsg_sample_run_batch call, or the stage-by-stage launches (_run_stagewise).
+    def _prepare(self, image, segmentation, seeds, genparams, arena, segmentation_u8=None):
         if genparams:
             genparams = self._validated_genparams(genparams)
         dev = self.device
         ig, sd = self.intensity_generator, self.spatial_deform
-        with _rng.use(self.rng):
-            # ---------------- host: every random draw, in the reference's order ----------------
-            labels, label_parts, gmm_plan, selected_seeds = None, None, None, {}
-            if seeds is not None:
-                gs = genparams.get("selected_seeds", {})
-                if hasattr(seeds, "parts") and ig.meta_labels <= 4:  # device-resident SeedBank
-                    m2s = ig.draw_subclusters(gs)
-                    label_parts, selected_seeds = seeds.parts(m2s), {"mlabel2subclusters": m2s}
-                    shape = tuple(label_parts[0].shape)
-                else:
-                    labels, selected_seeds = ig.load_seeds(seeds=seeds, genparams=gs)
-                    shape = tuple(labels.shape)
-                gmm_plan = ig.plan_intensities(shape, genparams.get("seed_intensities", {}))
+        c = _Ctx()
+        c.arena, c.image, c.segmentation, c.segmentation_u8, c.genparams = arena, image, segmentation, segmentation_u8, genparams
+        c.labels, c.label_parts, c.gmm_plan, c.selected_seeds = None, None, None, {}
+        if seeds is not None:
+            gs = genparams.get("selected_seeds", {})
+            if hasattr(seeds, "parts") and ig.meta_labels <= 4:  # device-resident SeedBank
+                m2s = ig.draw_subclusters(gs)
+                c.label_parts, c.selected_seeds = seeds.parts(m2s), {"mlabel2subclusters": m2s}
+                shape = tuple(c.label_parts[0].shape)
             else:
-                if image is None:
-                    raise ValueError(
-                        "If no seeds are passed, an image must be loaded to be used as intensity prior!")
-                shape = tuple(image.shape)
-            dplan, g, bplan, rplan, nplan = self._draw_plans(shape, genparams)
+                c.labels, c.selected_seeds = ig.load_seeds(seeds=seeds, genparams=gs)
+                shape = tuple(c.labels.shape)
+            c.gmm_plan = ig.plan_intensities(shape, genparams.get("seed_intensities", {}))
+        else:
+            if image is None:
+                raise ValueError(
+                    "If no seeds are passed, an image must be loaded to be used as intensity prior!")
+            shape = tuple(image.shape)
+        c.shape = shape
+        c.dplan, c.g, c.bplan, c.rplan, c.nplan = self._draw_plans(shape, genparams)
+        dplan, bplan, rplan = c.dplan, c.bplan, c.rplan
 
-            # ---------------- one upload of all small arrays ------------------------------------
+        c.sb = sd.make_spec(dplan, shape, flip_in_kernel=True, arena=arena) if dplan.active else None
+        c.bias_tabs, c.bias_off = None, None
+        if bplan.active:
+            c.bias_tabs = K.device_tables_for(self.biasfield.tables(bplan, shape), dev)
+            c.bias_off = arena.add(bplan.grid.numpy())
+        c.rs_tabs = c.back_tabs = None
+        if rplan.active:
+            c.rs_tabs = K.DeviceTables(rplan.tabs, dev, arena)
+            # zoom-back by 1 / factors, factors = new_size / size (tables.resample_plan): a function of the two shapes
+            bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
+            c.back_tabs = K.device_tables_for(bt, dev)
+        c.mm_off = arena.add(_MM8_INIT)  # the sample's min/max keys arrive initialised with its parameters
+        c.gm_off = None
+        if c.gmm_plan is not None:
+            c.gm_off = (arena.add(c.gmm_plan.mus.numpy()), arena.add(c.gmm_plan.sigmas.numpy()), c.gmm_plan.mus.numel())
+        c.has_art = any(a is not None for a in self.artifacts.values())
+        c.keep = []
+        return c
+
+    def _resolve(self, c):
+        f32_view = c.arena.f32
+        c.seed_intensities, c.mus, c.sigmas = {}, None, None
+        if c.gmm_plan is not None:
+            c.mus, c.sigmas = f32_view(c.gm_off[0], (c.gm_off[2],)), f32_view(c.gm_off[1], (c.gm_off[2],))
+            c.seed_intensities = {"mus": c.mus, "sigmas": c.sigmas}
+        c.bias_dev = f32_view(c.bias_off, tuple(c.bplan.grid.shape)) if c.bplan.active else None
+        c.gam = float(c.g) if c.g is not None else None
+        c.spec = c.sb.build() if c.dplan.active else None
+
+    def _synth_params(self, c, artifacts):
+        return self._params(c.selected_seeds, c.seed_intensities, c.dplan, c.g, c.bplan, c.rplan, c.nplan, artifacts)
+
+    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
+        with _rng.use(self.rng):
             arena = T.Arena()
-            sb = sd.make_spec(dplan, shape, flip_in_kernel=True, arena=arena) if dplan.active else None
-            bias_tabs, bias_off = None, None
-            if bplan.active:
-                bias_tabs = K.device_tables_for(self.biasfield.tables(bplan, shape), dev)
-                bias_off = arena.add(bplan.grid.numpy())
-            rs_tabs = back_tabs = None
-            if rplan.active:
-                rs_tabs = K.DeviceTables(rplan.tabs, dev, arena)
-                # zoom-back by 1 / factors, factors = new_size / size (tables.resample_plan): a function of the two shapes
-                bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
-                back_tabs = K.device_tables_for(bt, dev)
-            mm_off = arena.add(_MM8_INIT)  # the sample's min/max keys arrive initialised with its parameters
-            slots_off = None  # arena.add(_MM_SLOTS_INIT): sharded K9 keys measured no faster than the single pair (fsg_zoom.hip)
-            gm_off = None
-            if gmm_plan is not None:
-                gm_off = (arena.add(gmm_plan.mus.numpy()), arena.add(gmm_plan.sigmas.numpy()), gmm_plan.mus.numel())
-            arena.upload(dev)
-
-            f32_view = arena.f32
-
-            # ---------------- device ----------------------------------------------------------
-            seed_intensities = {}
-            if gmm_plan is not None:
-                mus, sigmas = f32_view(gm_off[0], (gm_off[2],)), f32_view(gm_off[1], (gm_off[2],))
-                seed_intensities = {"mus": mus, "sigmas": sigmas}
-            bias_dev = f32_view(bias_off, tuple(bplan.grid.shape)) if bplan.active else None
-            gam = float(g) if g is not None else None
-            has_art = any(a is not None for a in self.artifacts.values())
-            spec = sb.build() if dplan.active else None
-
-            if (self.native_pipeline and label_parts is not None and image is None and not has_art
-                    and segmentation_u8 is None):
-                native = self._run_native(shape, label_parts, mus, sigmas, gmm_plan, spec, segmentation, gam, bias_dev,
-                                          bias_tabs, rplan, rs_tabs, back_tabs, nplan, scale01, arena.ptr(mm_off),
-                                          mm_slots_ptr=(arena.ptr(slots_off) if slots_off is not None else None))
+            c = self._prepare(image, segmentation, seeds, genparams, arena, segmentation_u8)
+            arena.upload(self.device)
+            self._resolve(c)
+            if self._native_ok(c):
+                native = self._run_native(c, scale01)
                 if native is not None:
-                    return native[0], native[1], None, self._params(selected_seeds, seed_intensities, dplan, g, bplan,
-                                                                    rplan, nplan, {})
+                    return native[0], native[1], None, self._synth_params(c, {})
+            return self._run_stagewise(c, scale01)
 
+    def sample_batch(self, items, genparams_list=None, scale01: bool = False, streams: int = 1, lazy_items: int | None = None):
+        """B samples with one parameter upload and one native call.
+
+        items: sequence of (image | None, segmentation, seeds) as for `sample`; the host draws are made sample by sample
+        in this order, so the results are bit-identical to B consecutive `sample` calls under the same generator state
+        (reference: B x FetalSynthGen.sample, generator/model.py:231-276).
+        Returns (images (B,H,W,D) float32, labels (B,H,W,D) float32, [image_b | None], [synth_params_b]) -- one tensor per
+        output, so a stager moves the batch with one copy.  streams > 1: consecutive samples are enqueued round-robin on
+        that many side streams (their kernel tails overlap); the current stream waits for all of them before returning.
+        Samples outside the fused path's domain fall back to the per-sample path, with the draws already made.
+        lazy_items=B: `items` is an iterator of B entries consumed one at a time, each right before that sample's host
+        draws (callers that re-seed the global generators per sample, e.g. PrefetchingStream)."""
+        import ctypes as C
+
+        from .. import _lib
+
+        if lazy_items is None:
+            items = list(items)
+            B = len(items)
+        else:
+            B = int(lazy_items)
+        genparams_list = list(genparams_list) if genparams_list is not None else [{}] * B
+        if len(genparams_list) != B:
+            raise ValueError("genparams_list must have one entry per item")
+        dev = torch.device(self.device)
+        with _rng.use(self.rng):
+            arena = T.Arena()
+            ctxs = [self._prepare(img, seg, seeds, gp, arena) for (img, seg, seeds), gp in zip(items, genparams_list)]
+            if len(ctxs) != B:
+                raise ValueError(f"items yielded {len(ctxs)} entries, expected {B}")
+            arena.upload(self.device)
+            for c in ctxs:
+                self._resolve(c)
+            shapes = {c.shape for c in ctxs}
+            fused = B > 0 and len(shapes) == 1 and all(self._native_ok(c) for c in ctxs)
+            if fused:
+                for c in ctxs:
+                    self._native_operands(c)
+                shape = ctxs[0].shape
+                nstreams = max(1, min(int(streams), B))
+                main = torch.cuda.current_stream(dev)
+                side = self._side_streams(nstreams) if nstreams > 1 else [main]
+                need = max(self._rows_needed(c) for c in ctxs)
+                wss = []
+                for q in range(nstreams):  # one scratch set per stream the batch runs on
+                    with torch.cuda.stream(side[q]):
+                        wss.append(self._workspace(shape, need))
+                out_all = torch.empty((B, *shape), dtype=torch.float32, device=dev)
+                seg_all = torch.empty((B, *shape), dtype=torch.float32, device=dev)
+                plans = (_lib.SamplePlan * B)()
+                ok = True
+                for b, c in enumerate(ctxs):
+                    if c.spec is None:
+                        seg_all[b].copy_(c.seg)  # no deformation: labels pass through (same stream as the upload)
+                    ok = ok and self._fill_native_plan(plans[b], c, scale01, wss[b % nstreams], out_all[b], seg_all[b])
+                if ok:
+                    handles = (C.c_void_p * nstreams)()
+                    if nstreams > 1:
+                        fork = torch.cuda.Event()
+                        fork.record(main)
+                        for q in range(nstreams):
+                            side[q].wait_event(fork)
+                            handles[q] = side[q].cuda_stream
+                    else:
+                        handles[0] = K._stream(dev).value
+                    rc = _lib.load().fsg_sample_run_batch(plans, B, handles, nstreams)
+                    if nstreams > 1:
+                        for q in range(nstreams):
+                            join = torch.cuda.Event()
+                            join.record(side[q])
+                            main.wait_event(join)
+                    if rc not in (_lib.E_ALIGN, _lib.E_TOOBIG):
+                        _lib.check(rc, "fsg_sample_run_batch")
+                        return out_all, seg_all, [None] * B, [self._synth_params(c, {}) for c in ctxs]
+                    fused = False  # nothing usable was produced: per-sample path below (same plans, no new draws)
+            outs = []
+            for c in ctxs:
+                native = self._run_native(c, scale01) if self._native_ok(c) else None
+                outs.append((native[0], native[1], None, self._synth_params(c, {})) if native is not None
+                            else self._run_stagewise(c, scale01))
+        same = len({tuple(o[0].shape) for o in outs}) == 1 if outs else False
+        images = torch.stack([o[0] for o in outs]) if same else [o[0] for o in outs]
+        labels = torch.stack([o[1].float() for o in outs]) if same else [o[1] for o in outs]
+        return images, labels, [o[2] for o in outs], [o[3] for o in outs]
+
+    def _side_streams(self, n):
+        cur = self.__dict__.setdefault("_batch_streams", [])
+        while len(cur) < n:
+            cur.append(torch.cuda.Stream(device=torch.device(self.device)))
+        return cur[:n]
+
+    def _run_stagewise(self, c, scale01):
+        """Stage-by-stage launches of a prepared sample (images as intensity prior, SR-artifact stages, host label
+        tensors, uint8 label output, configurations outside the fused kernels' domain)."""
+        dev = self.device
+        sd = self.spatial_deform
+        image, segmentation, genparams = c.image, c.segmentation, c.genparams
+        gmm_plan, dplan, bplan, rplan, nplan = c.gmm_plan, c.dplan, c.bplan, c.rplan, c.nplan
+        mus, sigmas, gam, bias_dev, bias_tabs, spec = c.mus, c.sigmas, c.gam, c.bias_dev, c.bias_tabs, c.spec
+        rs_tabs, back_tabs, has_art = c.rs_tabs, c.back_tabs, c.has_art
+        if True:
             if gmm_plan is not None:
                 f = gmm_plan.field
                 z = f.device_tensor(dev) if f.host is not None else None
-                if label_parts is not None:
-                    output = K.gmm_sample_parts(label_parts, mus, sigmas, noise=z, seed=f.seed or 0,
+                if c.label_parts is not None:
+                    output = K.gmm_sample_parts(c.label_parts, mus, sigmas, noise=z, seed=f.seed or 0,
                                                 stream_id=f.stream_id)
                 else:
+                    labels = c.labels
                     if labels.dtype not in (torch.uint8, torch.int64):
                         labels = labels.long()
                     labels = labels.to(dev).contiguous()
@@ -411,7 +547,7 @@ class FetalSynthGen:
             if dplan.active:
                 image, segmentation, output = sd.run(dplan, image, segmentation, output, spec=spec,
                                                      mm6=K.coords_floormin(spec, mm8), gamma=gam, bias=bias_dev,
-                                                     bias_tabs=bias_tabs, segmentation_u8=segmentation_u8)
+                                                     bias_tabs=bias_tabs, segmentation_u8=c.segmentation_u8)
             else:
                 segmentation = segmentation.to(dev)
                 if gam is not None:
@@ -438,5 +574,4 @@ class FetalSynthGen:
             if scale01 and has_art:
                 output = K.scale(output.contiguous(), K.reduce_minmax(output.contiguous()), mode=1)
 
-        synth_params = self._params(selected_seeds, seed_intensities, dplan, g, bplan, rplan, nplan, artifacts)
-        return output, segmentation, image, synth_params
+        return output, segmentation, image, self._synth_params(c, artifacts)

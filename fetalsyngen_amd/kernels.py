@@ -472,6 +472,15 @@ def gamma(x, g: float) -> torch.Tensor:
     return out
 
 
+def cast_f16(x) -> torch.Tensor:
+    """float32 -> float16 copy (round to nearest even) by fsg_cast_f32_to_f16: the optional half-precision image."""
+    _need_gpu(x)
+    x = _f32(x).contiguous()
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().fsg_cast_f32_to_f16(_p(x), x.numel(), _p(out), _stream(x)), "fsg_cast_f32_to_f16")
+    return out
+
+
 def bias_mul(x, bias, bias_tabs: DeviceTables) -> torch.Tensor:
     _need_gpu(x, bias)
     nx, ny, nz = _dims3(_f32(x))

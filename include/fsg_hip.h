@@ -429,6 +429,13 @@ typedef struct fsg_sample_plan {
   int32_t mm_nslots;
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
+/* B samples with one call: plan b runs on streams[b % nstreams] (hipStream_t handles).  The caller orders those streams
+ * behind the upload of every plan's parameters and waits for them afterwards; per sample the work is exactly
+ * fsg_sample_run's (reference: B consecutive FetalSynthGen.sample calls, generator/model.py:231-276; the reference's
+ * DataLoader collates B such samples, data/datasets.py:310-325, docs/datasets.md:4-6). */
+int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams);
+/* float32 -> float16 (round to nearest even) copy of a volume: the optional half-precision image of the output side. */
+int fsg_cast_f32_to_f16(const float* x, size_t n, void* out_f16, void* stream);
 
 /* hipEvent helpers for ctypes callers (timing on the launch stream). elapsed_ms synchronises on `end`. */
 void* fsg_event_create(void);

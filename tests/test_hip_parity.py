@@ -1058,6 +1058,94 @@ def test_config4_384_hot_path_properties(K):
             assert abs(float(mean[l]) - float(mus[l])) < 0.05 and abs(float(var[l]) ** 0.5 - float(sig[l])) < 0.05
 
 
+@pytest.mark.parametrize("prob", [1.0, 0.6])
+def test_sample_batch_equals_consecutive_samples(K, tmp_path, prob):
+    """B volumes per call.  `sample_batch` (one parameter upload, one fsg_sample_run_batch call, 1 or 2 HIP
+    streams) must reproduce B consecutive `sample` calls bit for bit -- images, labels, synth_params and the position of
+    both host generators afterwards -- for B in {1, 4}, with every gate on and with gates failing at random."""
+    from tests.util_bids import write_tree
+    from fetalsyngen_amd.data.datasets import FetalSynthDataset, SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (48, 40, 56)
+    subjects = []
+    for v in range(4):
+        seg, seeds = make_seed_volumes(shape, v)
+        subjects.append((dev(seg), SeedBank(seeds, DEV)))
+    gen = make_generator(shape, DEV, rng="device", prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.03, 0.12))
+
+    def run_single(order):
+        np.random.seed(21)
+        torch.manual_seed(21)
+        res = [gen.sample(None, subjects[k][0], subjects[k][1]) for k in order]
+        return res, next_draws_pair()
+
+    def next_draws_pair():
+        return float(np.random.rand()), float(torch.rand(1))
+
+    for order in ([2], [0, 3, 1, 2]):
+        want, tail = run_single(order)
+        for streams in (1, 2):
+            np.random.seed(21)
+            torch.manual_seed(21)
+            out, lab, imgs, params = gen.sample_batch([(None, subjects[k][0], subjects[k][1]) for k in order], streams=streams)
+            assert next_draws_pair() == tail
+            assert tuple(out.shape) == (len(order), *shape) and imgs == [None] * len(order)
+            for b, (wo, wl, _wi, wp) in enumerate(want):
+                assert torch.equal(out[b], wo) and torch.equal(lab[b], wl), (order, streams, b)
+                assert wp["resample_params"] == params[b]["resample_params"] and wp["noise_params"] == params[b]["noise_params"]
+                assert torch.equal(wp["seed_intensities"]["mus"], params[b]["seed_intensities"]["mus"])
+    # dataset level: the collated contract, and scale01 like __getitem__
+    bids, seed_dir = write_tree(tmp_path, (32, 32, 32), ["sub-a", "sub-b", "sub-c"])
+    g2 = make_generator((32, 32, 32), DEV, rng="device", prob=prob, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+    ds = FetalSynthDataset(str(bids), g2, str(seed_dir), None)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    singles = [ds[i] for i in (2, 0, 1)]
+    np.random.seed(5)
+    torch.manual_seed(5)
+    batch, gps = ds.sample_batch([2, 0, 1], streams=2)
+    assert batch["image"].shape == (3, 1, 32, 32, 32) and batch["label"].dtype == torch.int64 and not batch["image"].is_cuda
+    assert batch["name"] == [s_["name"] for s_ in singles] and len(gps) == 3 and gps[1]["idx"] == 0
+    for b, s_ in enumerate(singles):
+        assert torch.equal(batch["image"][b], s_["image"]) and torch.equal(batch["label"][b], s_["label"])
+
+
+def test_prefetching_stream_batched_and_half_precision(K, tmp_path):
+    """Batched streaming (B samples per native call, one D2H copy per tensor and batch) yields exactly the per-sample
+    stream's samples whatever the batch size (ragged last batch included); the optional float16 image is the float32 image
+    rounded to nearest even."""
+    from tests.util_bids import write_tree
+    from fetalsyngen_amd.data.datasets import FetalSynthDataset
+    from fetalsyngen_amd.data.staging import PrefetchingStream
+
+    shape = (32, 32, 32)
+    bids, seed_dir = write_tree(tmp_path, shape, ["sub-a", "sub-b"])
+    gen = make_generator(shape, DEV, rng="device", prob=0.9, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2))
+    ds = FetalSynthDataset(str(bids), gen, str(seed_dir), None)
+    ds.sample(0), ds.sample(1)
+    n = 11
+    want = [(d["image"].clone(), d["label"].clone(), d["name"]) for d in PrefetchingStream(ds, range(n), base_seed=4, depth=2)]
+    for B, streams in ((4, 1), (3, 2), (16, 2)):
+        got = []
+        for item in PrefetchingStream(ds, range(n), base_seed=4, depth=2, batch_size=B, batch_streams=streams):
+            assert item["image"].dim() == 5 and item["image"].shape[1] == 1 and len(item["name"]) == item["image"].shape[0]
+            for b in range(item["image"].shape[0]):
+                got.append((item["image"][b].clone(), item["label"][b].clone(), item["name"][b]))
+        assert len(got) == n
+        for (wi, wl, wn), (gi, gl, gn) in zip(want, got):
+            assert wn == gn and torch.equal(wi, gi) and torch.equal(wl, gl)
+    dev_items = list(PrefetchingStream(ds, range(n), base_seed=4, to_host=False, batch_size=4))
+    assert dev_items[0]["image"].is_cuda and dev_items[0]["label"].dtype == torch.uint8 and dev_items[-1]["image"].shape[0] == 3
+    assert torch.equal(dev_items[0]["image"][1].cpu(), want[1][0])
+    half = [d for d in PrefetchingStream(ds, range(n), base_seed=4, depth=2, batch_size=4, image_dtype=torch.float16,
+                                         label_dtype=torch.uint8)]
+    assert half[0]["image"].dtype == torch.float16 and half[0]["label"].dtype == torch.uint8
+    assert torch.equal(half[0]["image"][2], want[2][0].to(torch.float16)) and torch.equal(half[0]["label"][2].long(), want[2][1])
+    x = torch.rand(1000003, device=DEV) * 3 - 1
+    assert torch.equal(K.cast_f16(x), x.to(torch.float16))
+
+
 def test_workspace_eviction_across_streams(K):
     """More (shape, stream) keys than `FetalSynthGen._ws` keeps (4): samples interleaved over 6 streams evict
     each other's scratch volumes while kernels are still in flight; every result must equal the same sample
