@@ -570,10 +570,18 @@ def run(args, rank, world, local):
         c5 = {"workload": f"BASELINE configs[4]: {n_stream} volumes per rank streamed through PrefetchingStream into a consumer "
                           f"that touches every image ({args.size}^3, 4 cached subjects per rank)", "scaling": "weak",
               "volumes_per_rank": n_stream}
-        for key, kw in (("cpu_contract", dict(to_host=True, depth=3)), ("device_resident", dict(to_host=False))):
+        import torch as _t
+
+        modes = (("cpu_contract", dict(to_host=True, depth=3)),
+                 ("cpu_contract_batched", dict(to_host=True, depth=2, batch_size=4, batch_streams=2)),
+                 ("cpu_f16_u8_batched", dict(to_host=True, depth=2, batch_size=4, batch_streams=2, image_dtype=_t.float16,
+                                             label_dtype=_t.uint8)),
+                 ("device_resident", dict(to_host=False)),
+                 ("device_resident_batched", dict(to_host=False, batch_size=4, batch_streams=2)))
+        for key, kw in modes:
             acc = torch.zeros((), dtype=torch.float64, device=device)
             host_acc = 0.0
-            for item in PrefetchingStream(ds, idx[:8], base_seed=99, **kw):  # warm-up (ring allocation, pinning)
+            for item in PrefetchingStream(ds, idx[:16], base_seed=99, **kw):  # warm-up (ring allocation, pinning)
                 pass
             torch.cuda.synchronize()
             R.barrier()
@@ -587,9 +595,12 @@ def run(args, rank, world, local):
             torch.cuda.synchronize()
             R.barrier()
             dts = R.max(time.perf_counter() - t0)
-            c5[key] = {"volumes_per_s": round(world * n_stream / dts, 1), "s": round(dts, 3),
-                       "outputs": ("float32 image (1,H,W,D) + int64 labels on the CPU (pinned ring), reference data/datasets.py:315-323"
-                                   if key == "cpu_contract" else "float32 image + uint8 labels in HBM")}
+            outputs = {"cpu_contract": "float32 image (1,H,W,D) + int64 labels on the CPU (pinned ring), reference data/datasets.py:315-323",
+                       "cpu_contract_batched": "the same contract, 4 samples per native call on 2 HIP streams, collated (4,1,H,W,D), one D2H copy per tensor and batch",
+                       "cpu_f16_u8_batched": "opt-in: float16 image + uint8 labels on the CPU (48 MiB instead of 192 MiB per volume), batches of 4",
+                       "device_resident": "float32 image + uint8 labels in HBM",
+                       "device_resident_batched": "float32 image + uint8 labels in HBM, 4 samples per native call on 2 HIP streams"}[key]
+            c5[key] = {"volumes_per_s": round(world * n_stream / dts, 1), "s": round(dts, 3), "outputs": outputs}
         del ds
 
     reports = R.gather({"rank": rank, "device": device, "name": props.name, "uuid": str(getattr(props, "uuid", "")) or None,
