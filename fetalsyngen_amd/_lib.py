@@ -92,6 +92,7 @@ class SamplePlan(C.Structure):
         ("ev_blur_end", C.c_void_p),
         ("mm_slots", C.c_void_p),
         ("mm_nslots", C.c_int32),
+        ("seg_in_u8", C.c_void_p),
     ]
 
 

@@ -75,7 +75,11 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       }
       FSG_TRY(rc);
     }
-    FSG_TRY(fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream));
+    int rw = FSG_E_ALIGN;
+    if (p->seg_in_u8)  // uint8 copy of the labels: 1 B/voxel gathered instead of 4 (same output)
+      rw = fsg_warp_f32_u8_to_f32(&d, p->mm8, cur, other, p->seg_in_u8, p->seg_out, &p->epi, stream);
+    if (rw == FSG_E_ALIGN) rw = fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream);
+    FSG_TRY(rw);
     float* t = cur; cur = other; other = t;
   } else {
     if (has_gamma) {

@@ -161,6 +161,10 @@ class FetalSynthGen:
             p.deform_active = 1
             p.deform = spec.c
             p.seg_in, p.seg_out = seg.data_ptr(), seg_out.data_ptr()
+            # only for a caller-owned device tensor (stable identity): a converted copy would be a new cache entry per call
+            twin = self._label_twin(seg) if seg is c.segmentation else None
+            if twin is not None:
+                p.seg_in_u8 = twin.data_ptr()
         p.epi = K._epilogue(c.gam, c.bias_dev, c.bias_tabs, shape)
         c.keep.append(p.epi)
         if rplan.active:
@@ -191,6 +195,22 @@ class FetalSynthGen:
         p.mm8, p.mm8_preset = c.arena.ptr(c.mm_off), 1
         p.out = out.data_ptr()
         return True
+
+    def _label_twin(self, seg):
+        """uint8 copy of a float32 label volume whose values are integers in 0..255 (dseg volumes always are), cached per
+        tensor (storage address, size, in-place version): the fused warp then gathers 1 B/voxel instead of 4, the output
+        stays float32.  The one-time check synchronises; None when the volume is not integer valued."""
+        cache = self.__dict__.setdefault("_twins", {})
+        key = (seg.data_ptr(), seg.numel(), seg._version)
+        hit = cache.get(key)
+        if hit is None:
+            r = seg.round()
+            ok = bool(torch.equal(r, seg)) and float(seg.min()) >= 0 and float(seg.max()) <= 255
+            hit = (seg.to(torch.uint8) if ok else None, seg)  # the source tensor is kept so that its address stays taken
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            cache[key] = hit
+        return hit[0]
 
     def _native_ok(self, c) -> bool:
         return (self.native_pipeline and c.label_parts is not None and c.image is None and not c.has_art

@@ -427,6 +427,8 @@ typedef struct fsg_sample_plan {
   int32_t* mm_slots;             /* optional: mm_nslots initialised slots (see fsg_zoom3d_minmax_sharded_f32) for the min / max
                                     of the zoom-back; the [0,1] scaling then reads them instead of mm8[3..4] */
   int32_t mm_nslots;
+  const uint8_t* seg_in_u8;      /* optional uint8 copy of seg_in (same values): the label gather then reads 1 B/voxel
+                                    (fsg_warp_f32_u8_to_f32); seg_in stays required as the fallback source */
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
 /* B samples with one call: plan b runs on streams[b % nstreams] (hipStream_t handles).  The caller orders those streams
