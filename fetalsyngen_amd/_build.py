@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     cc = hipcc()
-    objs = []
+    objs, jobs = [], []
     build_dir = PKG / "build"
     build_dir.mkdir(exist_ok=True)
     for s in SOURCES:
@@ -45,9 +45,17 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         deps = [CSRC / s, CSRC / "fsg_common.h", PKG.parent / "include" / "fsg_hip.h", Path(__file__)]
         if not force and not EXTRA and o.exists() and all(d.stat().st_mtime < o.stat().st_mtime for d in deps):
             continue  # object is newer than its source and the shared headers
+        jobs.append(cmd)
+    # the translation units are independent: compile up to four at a time (hipcc is single-threaded per file)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(len(jobs), 1))) as pool:
+        list(pool.map(run, jobs))
     tmp = LIB.with_suffix(".so.tmp")
     subprocess.run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", str(tmp)], check=True)
     os.replace(tmp, LIB)
