@@ -499,6 +499,37 @@ __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY,
   }
 }
 
+// Correctly rounded v / d for a divisor that is uniform over the launch (K9b divides 16.8 M voxels by the same maximum).
+// r = RN(1/d) once; per value q = RN(v r), e = v - q d (exact in one FMA for a faithful q), result RN(q + e r).  With a
+// correctly rounded reciprocal this is the correctly rounded quotient (Markstein's theorem) except when d's significand is all
+// ones; outside a safe exponent window for d or q the IEEE division runs instead (exec-masked, empty in practice).  ~4 VALU
+// instead of the ~10 of the division expansion; bit-identical to `v / d` (tests/test_hip_parity.py::test_uniform_division...).
+// per-output evaluation for the slab kernel's rare "window does not fit" path; out of line so that its registers do not
+// count against the kernel's hot loop
+__device__ __attribute__((noinline)) float zoom_slab_slow(const float* src, int sy, int sz, fsg_tap a, fsg_tap b, fsg_tap c) {
+  return fsg_tab_interp<1>(src, sy, sz, 0, a, b, c);
+}
+
+struct UniDiv {
+  float d, r;
+  bool fast;
+};
+__device__ __forceinline__ UniDiv unidiv_make(float d) {
+  UniDiv u;
+  u.d = d;
+  u.r = 1.0f / d;
+  const unsigned bits = __builtin_bit_cast(unsigned, d);
+  u.fast = d > 1e-18f && d < 1e18f && (bits & 0x7FFFFFu) != 0x7FFFFFu;
+  return u;
+}
+__device__ __forceinline__ float unidiv(const UniDiv& u, float v) {
+  const float q = v * u.r;
+  const float e = __builtin_fmaf(-q, u.d, v);
+  const float q1 = __builtin_fmaf(e, u.r, q);
+  const bool ok = u.fast && ((q > 1e-18f && q < 1e18f) || v == 0.f);
+  return ok ? q1 : v / u.d;
+}
+
 // ---- slab variant (default for the passes without a noise draw: K9a min/max, K9b normalise, plain zoom) --------
 // The row kernels above are bound by a chain of dependent global round trips per output row (taps -> four source rows
 // -> LDS -> outputs, ~3.6 us per row and wave: profiles/r01_r_pmc_bench_kernels.json), the tile kernel by four LDS reads
@@ -511,7 +542,10 @@ __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY,
 //      four outputs stay in registers when dz <= 256), one 16-byte store.
 // Blend order x -> y -> z with separate multiplies and adds: bit-identical to fsg_tab_interp<1> and to the other kernels.
 template <int EPI>
-__global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
+#ifndef FSG_SLAB_WAVES
+#define FSG_SLAB_WAVES 1  // minimum waves per SIMD asked of the register allocator (tuning: tools/ab builds)
+#endif
+__global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
   // domain (checked by the launcher): sz <= 256 and dz <= 256 -- a lane owns source elements lane + 64 c (c < 4) in the
   // y stage and outputs 4 lane .. 4 lane + 3 in the z stage, everything unrolled
   extern __shared__ __attribute__((aligned(16))) float zt_smem[];
@@ -522,13 +556,10 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
   __shared__ float red[2][4];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int tiles_y = (Z.dy + TY - 1) / TY;
-  const int ntiles = Z.dx * tiles_y;
   const int nb = gridDim.x;
-  // workgroup -> contiguous run of tiles, runs dealt so that every XCD (blockIdx % 8) works on one slab of x planes.
-  // The min/max pass is launched with fewer workgroups than tiles: its two global keys are ONE address each, and 2 gated
-  // atomics per tile from 4 096 workgroups cost more than the whole evaluation (profiles/r02_b_zoom_experiments.txt).
-  const int wg = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int per = (ntiles + nb - 1) / nb;
+  const int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous x slabs
+  const int i = tile / tiles_y, jt = tile - i * tiles_y;
+  const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
   float lo = INFINITY, hi = -INFINITY;
   float mnq = 0.f, den = 1.f, mx = 1.f;
   if (EPI == EPI_NORM) {
@@ -537,6 +568,7 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
     mnq = mn / mx;
     den = 1.0f - mnq;
   }
+  const UniDiv ud = unidiv_make(mx);
   // the z taps of this lane's four outputs: the same for every row of every tile
   int zlo[4], zhi[4];
   float zwl[4], zwh[4];
@@ -554,10 +586,6 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
   const bool dst16 = (Z.dz & 3) == 0 && ((((uintptr_t)Z.dst) & 15) == 0);
   const bool full = lane * 4 + 3 < Z.dz;
   float* y = yr + wave * Z.sz;
-  for (int tile = wg * per; tile < min(ntiles, (wg + 1) * per); ++tile) {
-  const int i = tile / tiles_y, jt = tile - i * tiles_y;
-  const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
-  __syncthreads();  // previous tile's window and taps are no longer read
   if (tid < 64) {
     fsg_tap t = fsg_tap{-1, 0, 0.f, 0.f};
     if (tid < nj) {
@@ -614,7 +642,11 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
     } else if (EPI == EPI_NORM) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
+#ifdef FSG_NO_UNIDIV
         float t = v[u] / mx;
+#else
+        float t = unidiv(ud, v[u]);
+#endif
         if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : (t - mnq) / den);
         v[u] = t;
       }
@@ -666,12 +698,11 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (b.lo >= 0) {
         for (int u = 0; u < 4; ++u)
-          if (zok[u]) v[u] = fsg_tab_interp<1>(Z.src, Z.sy, Z.sz, 0, a, b, fsg_tap{zlo[u], zhi[u], zwl[u], zwh[u]});
+          if (zok[u]) v[u] = zoom_slab_slow(Z.src, Z.sy, Z.sz, a, b, fsg_tap{zlo[u], zhi[u], zwl[u], zwh[u]});
       }
       emit(jj, v);
     }
   }
-  }  // tiles of this workgroup
   if (EPI == EPI_MINMAX) {
     lo = fsg_wave_min(lo);
     hi = fsg_wave_max(hi);
@@ -684,7 +715,6 @@ __global__ __launch_bounds__(256) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY,
   }
 }
 
-int g_zoom_mm_blocks = 1024;   // workgroups of the slab kernel's min/max pass (FSG_ZOOM_MM_BLOCKS overrides, tuning only)
 int g_zoom_ty = 16;            // output y rows per workgroup of zoom_tile_kernel
 int g_zoom_cap = 12288;        // LDS floats for the x-blended source window (48 KB)
 
@@ -727,9 +757,7 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     const long long total = est + 4LL * Z.sz;  // window + the four waves' rows
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;
-      int nblk = Z.dx * tiles_y;
-      if (EPI == EPI_MINMAX && E.mm_shards <= 1 && nblk > g_zoom_mm_blocks) nblk = g_zoom_mm_blocks;  // unsharded keys: fewer same-address atomics
-      hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3((unsigned)nblk), dim3(256), (size_t)total * sizeof(float),
+      hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), (size_t)total * sizeof(float),
                          fsg_stream(stream), Z, E, TY, (int)est);
       FSG_RETURN_LAUNCH();
     }
@@ -806,7 +834,6 @@ int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_ta
   E.mm_out = mm;
   E.mm_shards = 1;
   if (getenv("FSG_DIAG_NO_MM_ATOMICS")) E.norm_mode = 77;  // DIAGNOSTIC (timing only): results are wrong
-  if (const char* e = getenv("FSG_ZOOM_MM_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 65536) g_zoom_mm_blocks = v & ~7; }
   return launch1<EPI_MINMAX>(Z, E, stream);
 }
 

@@ -295,6 +295,50 @@ def test_zoom_tile_kernel_equals_row_kernels(K):
                 assert torch.equal(a, b), (shape, m, key)
 
 
+def test_uniform_division_in_k9b_is_the_ieee_quotient(K):
+    """K9b divides every voxel by the same maximum through a reciprocal + two FMAs (`unidiv`, fsg_zoom.hip) instead of the
+    IEEE division expansion.  Exhaustive over the significand: a 2^23-voxel volume holding EVERY float32 significand of one
+    binade goes through an identity zoom + normalise (mode 0: v / max) for divisors that include powers of two, all-ones
+    significands (where the shortcut is not valid and the kernel must fall back), tiny and huge values; the result must be the
+    correctly rounded quotient, bit for bit (numpy float32 division on the host; torch's device division is not used as
+    the reference: it is not the correctly rounded one on this build)."""
+    from fetalsyngen_amd import tables as T
+
+    shape = (128, 256, 256)
+    n = int(np.prod(shape))
+    assert n == 1 << 23
+    tabs, new = T.zoom_tables(shape, np.array([1.0, 1.0, 1.0]))
+    assert new == shape
+    zt = K.DeviceTables(tabs, DEV)
+    rs = np.random.RandomState(8)
+    divisors = [1.0, 2.0, 0.5, 255.0, 300.0, 3.0, 1e-3, 7e7,
+                float(np.float32(np.uint32(0x437FFFFF).view(np.float32))),   # 255.99998: significand all ones
+                float(np.float32(np.uint32(0x3FFFFFFF).view(np.float32))),   # 1.9999999
+                float(np.float32(np.uint32(0x3F800001).view(np.float32)))]   # 1 + ulp
+    divisors += [float(v) for v in (30 + 370 * rs.rand(12)).astype(np.float32)]
+    divisors += [float(np.uint32(b).view(np.float32)) for b in rs.randint(0x3D000000, 0x46000000, 12, dtype=np.int64).astype(np.uint32)]
+    mant = np.arange(n, dtype=np.uint32)
+    for exp_bits in (127, 120, 134):  # binades [1,2), [2^-7, 2^-6), [128, 256)
+        vals = (mant | np.uint32(exp_bits << 23)).view(np.float32).reshape(shape)
+        x = dev(vals)
+        # the host's float32 division is the reference (IEEE, correctly rounded); every divisor on the first binade, a
+        # subset on the others
+        for d in (divisors if exp_bits == 127 else divisors[:4] + divisors[8:11] + divisors[-3:]):
+            d32 = np.float32(d)
+            mm = torch.tensor([0, int(d32.view(np.int32))], dtype=torch.int32, device=DEV)  # keys of (min = +0.0, max = d)
+            got = host(K.zoom_normalise(x, zt, mm, 0))
+            want = vals / d32
+            assert np.array_equal(got, want), (exp_bits, d, int((got != want).sum()))
+    # zeros, denormals and mode 1 (min-max scaling on top)
+    tiny = np.concatenate([np.zeros(1000, np.float32), (np.arange(1, 5000, dtype=np.uint32)).view(np.float32),
+                           rs.rand(n - 5999).astype(np.float32) * 200]).astype(np.float32).reshape(shape)
+    x = dev(tiny)
+    d32 = np.float32(199.77)
+    mm = torch.tensor([int(np.float32(0.0).view(np.int32)), int(d32.view(np.int32))], dtype=torch.int32, device=DEV)
+    assert np.array_equal(host(K.zoom_normalise(x, zt, mm, 0)), tiny / d32)
+    assert np.array_equal(host(K.zoom_normalise(x, zt, mm, 1)), tiny / d32)  # min = 0: (t - 0) / 1
+
+
 def test_blur_yz_fused_equals_two_passes(K):
     """y + z pass in one launch (intermediate in LDS) against the two single-axis launches: bit-identical, for tile-ragged
     shapes and every radius 1..8; outside its domain (different taps per axis, nz % 4, radius > 8) it declines (None)."""
