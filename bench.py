@@ -486,10 +486,10 @@ def run(args, rank, world, local):
     bytes_launch = 8.0 * nvox
     achieved = bytes_launch / us_launch / 1e3 if nlaunch else 0.0
     # whole step: SURVEY 8(d) per-kernel algorithmic bytes with the fusions as built (gamma/bias in the warp epilogue: 0;
-    # K9+K10 one evaluation): K1 5 + warp 8 (image) + 8 (f32 labels) + blur 24 + K7 (4 + 4mu) + K9 (4mu + 4) B/voxel
+    # K9+K10 one evaluation): K1 5 + warp 8 (image) + 5 (uint8 label read, float32 label write) + blur 24 + K7 (4 + 4mu) + K9 (4mu + 4) B/voxel
     size_v = float(args.size)
     mu = float(np.mean([(int(size_v * 0.5 / s[0]) / size_v) ** 3 for s in mus_seen if s])) if mus_seen else 1.0
-    step_bytes = (53.0 + 8.0 * mu) * nvox
+    step_bytes = (50.0 + 8.0 * mu) * nvox
 
     result = {
         "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
@@ -505,7 +505,7 @@ def run(args, rank, world, local):
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: single {args.size}^3 label volume per step, full path, all gates on",
-                   "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation resident in HBM",
+                   "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation (and its cached uint8 copy, which the label gather reads) resident in HBM",
                    "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
                    "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams},
         "roofline": {"bound": "hbm",
@@ -521,7 +521,7 @@ def run(args, rank, world, local):
                      "effective_pass_GBps": round(8.0 * nvox * npass / max(blur_total_ms * 1e3, 1e-9) / 1e3, 1),
                      "axis_passes_per_sample": round(npass / max(len(sections), 1), 2),
                      "launches_per_sample": round(nlaunch / max(len(sections), 1), 2)},
-        "roofline_step": {"bound": "hbm", "bytes_per_voxel": "53 + 8*mu (K1 5, warp 16 with f32 labels, blur 24, K7 4+4mu, K9/K10 4+4mu)",
+        "roofline_step": {"bound": "hbm", "bytes_per_voxel": "50 + 8*mu (K1 5, warp 8 image + 1 uint8 label read + 4 float32 label write, blur 24, K7 4+4mu, K9/K10 4+4mu)",
                           "mu_mean": round(mu, 4), "algorithmic_bytes_per_step": int(step_bytes),
                           "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -158,6 +158,8 @@ SIGNATURES = {
     "fsg_sample_head_f32": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, C.POINTER(Deform), C.POINTER(Epilogue), P, I, P, P],
     "fsg_coords_floormin_rest_f32": [C.POINTER(Deform), P, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
+    "fsg_sample_plan_pack": [C.POINTER(SamplePlan), P, I, P, I, P],
+    "fsg_sample_pack_run": [P, I, P, I, P, P],
     "fsg_sample_run_batch": [C.POINTER(SamplePlan), I, C.POINTER(C.c_void_p), I],
     "fsg_cast_f32_to_f16": [P, SZ, P, P],
     "fsg_event_destroy": [P],

@@ -152,6 +152,84 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   return 0;
 }
 
+// The plan from two flat arrays instead of ~60 field writes through an FFI (the Python mirror spends 41 us filling the
+// struct field by field through ctypes: profiles/r02_c_host_phases.txt).  Index layout: FSG_PLAN_I_* / FSG_PLAN_F_* in
+// include/fsg_hip.h.  `taps`: 3 x FSG_PLAN_TAPS_STRIDE floats, row a = the Gaussian taps of axis a.
+extern "C" int fsg_sample_plan_pack(fsg_sample_plan* p, const int64_t* iv, int niv, const double* fv, int nfv,
+                                    const float* taps) {
+  if (!p || !iv || !fv || niv < FSG_PLAN_I_COUNT || nfv < FSG_PLAN_F_COUNT) return FSG_E_BADARG;
+  fsg_sample_plan q = {};
+  for (int a = 0; a < 3; ++a) q.shape[a] = (int32_t)iv[FSG_PLAN_I_SHAPE + a];
+  for (int a = 0; a < 4; ++a) q.label_parts[a] = (const uint8_t*)(uintptr_t)iv[FSG_PLAN_I_LABEL_PARTS + a];
+  q.mus = (const float*)(uintptr_t)iv[FSG_PLAN_I_MUS];
+  q.sigmas = (const float*)(uintptr_t)iv[FSG_PLAN_I_SIGMAS];
+  q.ntab = (int32_t)iv[FSG_PLAN_I_NTAB];
+  q.gmm_noise = (const float*)(uintptr_t)iv[FSG_PLAN_I_GMM_NOISE];
+  q.gmm_seed = (uint64_t)iv[FSG_PLAN_I_GMM_SEED];
+  q.gmm_stream = (uint64_t)iv[FSG_PLAN_I_GMM_STREAM];
+  q.deform_active = (int32_t)iv[FSG_PLAN_I_DEFORM_ACTIVE];
+  if (q.deform_active) {
+    for (int a = 0; a < 3; ++a) q.deform.shape[a] = q.shape[a];
+    for (int a = 0; a < 9; ++a) q.deform.A[a] = (float)fv[FSG_PLAN_F_A + a];
+    for (int a = 0; a < 3; ++a) {
+      q.deform.centre[a] = (float)fv[FSG_PLAN_F_CENTRE + a];
+      q.deform.c2[a] = (float)fv[FSG_PLAN_F_C2 + a];
+      q.deform.field_dims[a] = (int32_t)iv[FSG_PLAN_I_FIELD_DIMS + a];
+    }
+    q.deform.flip = (int32_t)iv[FSG_PLAN_I_FLIP];
+    q.deform.field = (const float*)(uintptr_t)iv[FSG_PLAN_I_FIELD];
+    q.deform.tx = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_FIELD_TABS];
+    q.deform.ty = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_FIELD_TABS + 1];
+    q.deform.tz = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_FIELD_TABS + 2];
+  }
+  q.seg_in = (const float*)(uintptr_t)iv[FSG_PLAN_I_SEG_IN];
+  q.seg_out = (float*)(uintptr_t)iv[FSG_PLAN_I_SEG_OUT];
+  q.seg_in_u8 = (const uint8_t*)(uintptr_t)iv[FSG_PLAN_I_SEG_IN_U8];
+  q.epi.gamma = (float)fv[FSG_PLAN_F_GAMMA];
+  for (int a = 0; a < 3; ++a) q.epi.bias_dims[a] = (int32_t)iv[FSG_PLAN_I_BIAS_DIMS + a];
+  q.epi.bias = (const float*)(uintptr_t)iv[FSG_PLAN_I_BIAS];
+  q.epi.bx = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_BIAS_TABS];
+  q.epi.by = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_BIAS_TABS + 1];
+  q.epi.bz = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_BIAS_TABS + 2];
+  q.resample_active = (int32_t)iv[FSG_PLAN_I_RESAMPLE_ACTIVE];
+  for (int a = 0; a < 3; ++a) {
+    q.low_shape[a] = (int32_t)iv[FSG_PLAN_I_LOW_SHAPE + a];
+    q.rs_tab[a] = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_RS_TABS + a];
+    q.back_tab[a] = (const fsg_tap*)(uintptr_t)iv[FSG_PLAN_I_BACK_TABS + a];
+    const int nt = (int)iv[FSG_PLAN_I_BLUR_NTAPS + a];
+    if (nt < 0 || nt > 129 || (nt > 0 && !taps)) return FSG_E_BADARG;
+    q.blur_ntaps[a] = nt;
+    for (int t = 0; t < nt; ++t) q.blur_taps[a][t] = taps[a * FSG_PLAN_TAPS_STRIDE + t];
+  }
+  q.noise_mode = (int32_t)iv[FSG_PLAN_I_NOISE_MODE];
+  q.noise = (const float*)(uintptr_t)iv[FSG_PLAN_I_NOISE];
+  q.noise_seed = (uint64_t)iv[FSG_PLAN_I_NOISE_SEED];
+  q.noise_stream = (uint64_t)iv[FSG_PLAN_I_NOISE_STREAM];
+  q.noise_std = (float)fv[FSG_PLAN_F_NOISE_STD];
+  q.scale01 = (int32_t)iv[FSG_PLAN_I_SCALE01];
+  q.ws0 = (float*)(uintptr_t)iv[FSG_PLAN_I_WS0];
+  q.ws1 = (float*)(uintptr_t)iv[FSG_PLAN_I_WS1];
+  q.ws_low = (float*)(uintptr_t)iv[FSG_PLAN_I_WS_LOW];
+  q.ws_rows = (float*)(uintptr_t)iv[FSG_PLAN_I_WS_ROWS];
+  q.row_stride = (int32_t)iv[FSG_PLAN_I_ROW_STRIDE];
+  q.mm8 = (int32_t*)(uintptr_t)iv[FSG_PLAN_I_MM8];
+  q.mm8_preset = (int32_t)iv[FSG_PLAN_I_MM8_PRESET];
+  q.out = (float*)(uintptr_t)iv[FSG_PLAN_I_OUT];
+  q.ev_blur_begin = (void*)(uintptr_t)iv[FSG_PLAN_I_EV_BEGIN];
+  q.ev_blur_end = (void*)(uintptr_t)iv[FSG_PLAN_I_EV_END];
+  q.mm_slots = (int32_t*)(uintptr_t)iv[FSG_PLAN_I_MM_SLOTS];
+  q.mm_nslots = (int32_t)iv[FSG_PLAN_I_MM_NSLOTS];
+  *p = q;
+  return 0;
+}
+
+// pack + run in one call (what the Python mirror's fast path uses per sample)
+extern "C" int fsg_sample_pack_run(const int64_t* iv, int niv, const double* fv, int nfv, const float* taps, void* stream) {
+  fsg_sample_plan p;
+  FSG_TRY(fsg_sample_plan_pack(&p, iv, niv, fv, nfv, taps));
+  return fsg_sample_run(&p, stream);
+}
+
 // B samples with one native call (B volumes per call for DataLoader-style consumers).  Plan b is enqueued on
 // streams[b % nstreams]; with nstreams > 1 consecutive samples overlap their kernel tails (the caller has ordered those
 // streams behind the upload of the plans' parameters and joins them afterwards).  Results are those of B fsg_sample_run

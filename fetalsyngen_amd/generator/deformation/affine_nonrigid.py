@@ -71,6 +71,17 @@ class SpatialDeformation:
                 cache.pop(next(iter(cache)))
         return hit
 
+    def _shape_lists(self, shape3):
+        """`_shape_constants` as Python floats: (centre as float32 values, room for the random shift as float64 values)."""
+        cache = self.__dict__.setdefault("_shape_cache_l", {})
+        hit = cache.get(shape3)
+        if hit is None:
+            _shp, centre32, room64 = self._shape_constants(shape3)
+            hit = cache[shape3] = (centre32.astype(np.float64).tolist(), room64.tolist())
+            if len(cache) > 16:
+                cache.pop(next(iter(cache)))
+        return hit
+
     # ---- host: random draws in the reference's order (ref :140-145, :248-263, :284, :303-318) ----
     def plan(self, image_shape, random_shift=True, genparams: dict = {}) -> DeformPlan:
         p = DeformPlan()

@@ -40,6 +40,11 @@ _MM_SLOTS_INIT[:, 0], _MM_SLOTS_INIT[:, 1] = 0x7F800000, -2139095041
 _MM_SLOTS_INIT.setflags(write=False)
 
 
+import os as _os
+
+_SLOW_PLAN = _os.environ.get("FSG_SLOW_PLAN", "0") == "1"  # field-by-field ctypes plan instead of the flat arrays (cross-check)
+
+
 class _Ctx:
     """One prepared sample: its plans, arena offsets and (after _resolve) device views."""
 
@@ -245,6 +250,160 @@ class FetalSynthGen:
         b2 = int(c.bias_dev.shape[2]) if c.bias_dev is not None else 0
         return 3 * f2 + b2 if c.spec is not None else 0
 
+    # ---- fast form of _resolve + _native_operands + _fill_native_plan + fsg_sample_run ---------------------------------
+    # Same plan, built as two flat arrays and handed over with ONE native call (fsg_sample_pack_run): filling the ctypes
+    # struct field by field cost 41 us per sample, the spec / view objects 28 us, the operand checks 16 us
+    # (profiles/r02_c_host_phases.txt).  tests/test_hip_parity.py::test_fast_plan_equals_field_by_field_plan compares the two
+    # plans byte for byte.  FSG_SLOW_PLAN=1 forces the field-by-field path.
+    _I = dict(SHAPE=0, LABEL_PARTS=3, MUS=7, SIGMAS=8, NTAB=9, GMM_NOISE=10, GMM_SEED=11, GMM_STREAM=12, DEFORM_ACTIVE=13,
+              FLIP=14, FIELD_DIMS=15, FIELD=18, FIELD_TABS=19, SEG_IN=22, SEG_OUT=23, SEG_IN_U8=24, BIAS_DIMS=25, BIAS=28,
+              BIAS_TABS=29, RESAMPLE_ACTIVE=32, LOW_SHAPE=33, RS_TABS=36, BACK_TABS=39, BLUR_NTAPS=42, NOISE_MODE=45, NOISE=46,
+              NOISE_SEED=47, NOISE_STREAM=48, SCALE01=49, WS0=50, WS1=51, WS_LOW=52, WS_ROWS=53, ROW_STRIDE=54, MM8=55,
+              MM8_PRESET=56, OUT=57, EV_BEGIN=58, EV_END=59, MM_SLOTS=60, MM_NSLOTS=61, COUNT=62)
+    _TAPS_STRIDE = 132
+
+    def _flat_buffers(self):
+        fb = self.__dict__.get("_flat")
+        if fb is None:
+            iv = np.zeros(self._I["COUNT"], dtype=np.int64)
+            fv = np.zeros(17, dtype=np.float64)
+            tb = np.zeros((3, self._TAPS_STRIDE), dtype=np.float32)
+            centre = (np.array(self.spatial_deform.size) - 1) / 2
+            fb = self._flat = dict(iv=iv, fv=fv, tb=tb, ivp=iv.ctypes.data, fvp=fv.ctypes.data, tbp=tb.ctypes.data,
+                                   centre=np.asarray(centre, dtype=np.float32).tolist(), validated=set())
+        return fb
+
+    def _flat_plan(self, c, scale01, out, seg_out, ws, events=None):
+        """The two flat arrays of prepared sample `c` (uploaded arena, no _resolve needed).  Returns False when the
+        sample is outside the fused path's domain (blur radius beyond the tap capacity)."""
+        I = self._I
+        fb = self._flat_buffers()
+        iv, fv, tb = [0] * I["COUNT"], [0.0] * 17, fb["tb"]
+        arena, base = c.arena, c.arena.base
+        shape = c.shape
+        iv[0:3] = shape
+        for q, part in enumerate(c.label_parts):
+            iv[I["LABEL_PARTS"] + q] = part.data_ptr()
+        iv[I["MUS"]], iv[I["SIGMAS"]], iv[I["NTAB"]] = base + c.gm_off[0], base + c.gm_off[1], c.gm_off[2]
+        f = c.gmm_plan.field
+        if f.host is not None:
+            z = f.device_tensor(torch.device(self.device))
+            c.keep.append(z)
+            iv[I["GMM_NOISE"]] = z.data_ptr()
+        else:
+            iv[I["GMM_SEED"]], iv[I["GMM_STREAM"]] = f.seed, f.stream_id
+        dplan = c.dplan
+        if dplan.active:
+            iv[I["DEFORM_ACTIVE"]] = 1
+            iv[I["FLIP"]] = int(bool(dplan.flip))
+            fv[0:9] = dplan.A.reshape(-1).tolist()
+            fv[9:12] = fb["centre"]
+            fv[12:15] = dplan.c2.to(torch.float32).tolist()
+            if c.sb.pending is not None:
+                off, fshape = c.sb.pending
+                iv[I["FIELD_DIMS"]:I["FIELD_DIMS"] + 3] = fshape[:3]
+                iv[I["FIELD"]] = base + off
+                iv[I["FIELD_TABS"]:I["FIELD_TABS"] + 3] = c.sb.tabs.ptrs_i
+            iv[I["SEG_IN"]], iv[I["SEG_OUT"]] = c.seg.data_ptr(), seg_out.data_ptr()
+            twin = self._label_twin(c.seg) if c.seg is c.segmentation else None
+            if twin is not None:
+                iv[I["SEG_IN_U8"]] = twin.data_ptr()
+        if c.g is not None:
+            fv[15] = float(np.float32(float(c.g)))
+        if c.bplan.active:
+            iv[I["BIAS_DIMS"]:I["BIAS_DIMS"] + 3] = c.bplan.grid.shape
+            iv[I["BIAS"]] = base + c.bias_off
+            iv[I["BIAS_TABS"]:I["BIAS_TABS"] + 3] = c.bias_tabs.ptrs_i
+        rplan, nplan = c.rplan, c.nplan
+        if rplan.active:
+            iv[I["RESAMPLE_ACTIVE"]] = 1
+            iv[I["LOW_SHAPE"]:I["LOW_SHAPE"] + 3] = rplan.new_size
+            iv[I["RS_TABS"]:I["RS_TABS"] + 3] = c.rs_tabs.ptrs_i
+            iv[I["BACK_TABS"]:I["BACK_TABS"] + 3] = c.back_tabs.ptrs_i
+            for a_ in range(3):
+                if rplan.stds[a_] > 0:
+                    taps = T.gaussian_taps(float(rplan.stds[a_]))
+                    n = len(taps)
+                    if n > 129:
+                        return False
+                    iv[I["BLUR_NTAPS"] + a_] = n
+                    tb[a_, :n] = taps
+        if nplan.active:
+            nf = nplan.field
+            fv[16] = nplan.std32
+            if nf.host is not None:
+                zn = nf.device_tensor(torch.device(self.device))
+                c.keep.append(zn)
+                iv[I["NOISE_MODE"]], iv[I["NOISE"]] = 1, zn.data_ptr()
+            else:
+                iv[I["NOISE_MODE"]], iv[I["NOISE_SEED"]], iv[I["NOISE_STREAM"]] = 2, nf.seed, nf.stream_id
+        iv[I["SCALE01"]] = int(bool(scale01))
+        iv[I["WS0"]], iv[I["WS1"]], iv[I["WS_LOW"]] = ws["ws0"].data_ptr(), ws["ws1"].data_ptr(), ws["low"].data_ptr()
+        if ws["rows"] is not None:
+            iv[I["WS_ROWS"]], iv[I["ROW_STRIDE"]] = ws["rows"].data_ptr(), ws["stride"]
+        iv[I["MM8"]], iv[I["MM8_PRESET"]] = base + c.mm_off, 1
+        iv[I["OUT"]] = out.data_ptr()
+        if events is not None:
+            iv[I["EV_BEGIN"]], iv[I["EV_END"]] = events
+        fb["iv"][:] = iv
+        fb["fv"][:] = fv
+        return True
+
+    def _fast_operands(self, c) -> bool:
+        """The operand checks of _native_operands, once per distinct (segmentation, seed volumes) set; False when the
+        segmentation needs a conversion (host tensor, other dtype): the field-by-field path handles that."""
+        seg = c.segmentation
+        dev = torch.device(self.device)
+        if not (torch.is_tensor(seg) and seg.is_cuda and seg.dtype == torch.float32 and seg.is_contiguous()):
+            return False
+        fb = self._flat_buffers()
+        key = (seg.data_ptr(), tuple(seg.shape)) + tuple(p.data_ptr() for p in c.label_parts)
+        if key not in fb["validated"]:
+            c.mus, c.sigmas = (c.arena.f32(c.gm_off[0], (c.gm_off[2],)), c.arena.f32(c.gm_off[1], (c.gm_off[2],)))
+            self._native_operands(c)  # raises on a mismatch
+            if c.seg is not seg:
+                return False
+            if len(fb["validated"]) > 4096:
+                fb["validated"].clear()
+            fb["validated"].add(key)
+        c.seg = seg
+        c.shape = tuple(int(v) for v in c.shape)
+        if c.gm_off[2] > 256 or c.gm_off[2] < 1:
+            raise ValueError(f"mus / sigmas tables of {c.gm_off[2]} entries (need 1..256)")
+        return True
+
+    def _run_native_fast(self, c, scale01):
+        """Prepared sample -> (image, labels) through fsg_sample_pack_run, or None (caller falls back)."""
+        from .. import _lib
+
+        if not self._fast_operands(c):
+            return None
+        dev = torch.device(self.device)
+        f2 = int(c.sb.pending[1][2]) if (c.dplan.active and c.sb.pending is not None) else 0
+        b2 = int(c.bplan.grid.shape[2]) if c.bplan.active else 0
+        ws = self._workspace(c.shape, 3 * f2 + b2 if c.dplan.active else 0)
+        out = torch.empty(c.shape, dtype=torch.float32, device=dev)
+        seg_out = torch.empty_like(c.seg) if c.dplan.active else c.seg
+        events = None
+        lib = _lib.load()
+        if self.blur_events is not None and c.rplan.active:
+            events = (lib.fsg_event_create(), lib.fsg_event_create())
+        if not self._flat_plan(c, scale01, out, seg_out, ws, events):
+            return None
+        if events is not None:
+            fbiv = self._flat["iv"]
+            nt = [int(fbiv[self._I["BLUR_NTAPS"] + a_]) for a_ in range(3)]
+            self.blur_events.append((events[0], events[1], [(a_, nt[a_] // 2) for a_ in range(3) if nt[a_]]))
+        fb = self._flat
+        rc = lib.fsg_sample_pack_run(fb["ivp"], self._I["COUNT"], fb["fvp"], 17, fb["tbp"], K._stream(dev))
+        if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
+            return None
+        _lib.check(rc, "fsg_sample_pack_run")
+        f32_view = c.arena.f32
+        c.mus, c.sigmas = f32_view(c.gm_off[0], (c.gm_off[2],)), f32_view(c.gm_off[1], (c.gm_off[2],))
+        c.seed_intensities = {"mus": c.mus, "sigmas": c.sigmas}
+        return out, seg_out
+
     def _run_native(self, c, scale01):
         """Enqueue prepared sample `c` with one fsg_sample_run call.  Returns (image, labels), or None when the
         configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
@@ -363,12 +522,119 @@ class FetalSynthGen:
         nplan = self.noise.plan(low_shape, genparams.get("noise_params", {}))
         return dplan, g, bplan, rplan, nplan
 
-    def plan_only(self, shape, genparams: dict = {}):
-        """Every host draw of one seeds-based sample, nothing enqueued (bench.py --dry-plan, host profiling)."""
+    def plan_only(self, shape, genparams: dict = {}, fast: bool | None = None):
+        """Every host draw of one seeds-based sample, nothing enqueued (bench.py --dry-plan, host profiling).
+        fast=None: the bulk-draw form when there are no genparams (what `_prepare` uses); False: the per-stage plan()s."""
         with _rng.use(self.rng):
+            if (fast is None and not genparams and not _SLOW_PLAN) or fast:
+                return self._draw_all_fast(tuple(shape))
             m2s = self.intensity_generator.draw_subclusters(genparams.get("selected_seeds", {}))
             gmm_plan = self.intensity_generator.plan_intensities(tuple(shape), genparams.get("seed_intensities", {}))
             return (m2s, gmm_plan) + self._draw_plans(tuple(shape), genparams)
+
+    def _draw_all_fast(self, shape):
+        """All host draws of a seeds-based sample WITHOUT genparams, same values and same generator states as
+        `draw_subclusters` + `plan_intensities` + `_draw_plans` (tests/test_host_plans.py::test_bulk_draws_equal_per_stage_plans),
+        with fewer interpreter round trips: numpy's legacy generator hands out the same doubles whether they are asked for one
+        `rand()` at a time or as `random_sample(n)`, and `randint(lo, hi, size=4)` equals four scalar calls, so the draws
+        between two gates are fetched in one call (gates still short-circuit: nothing behind a failed gate is drawn);
+        `torch.rand(2n)` equals two `torch.rand(n)`.  Scalars are combined as Python floats (the same IEEE doubles as the
+        0-d numpy arithmetic of the per-stage code)."""
+        from .augmentation.synthseg import BiasPlan, NoisePlan, ResamplePlan
+        from .deformation.affine_nonrigid import DeformPlan
+        from .intensity.rand_gmm import GMMPlan
+        from ..utils.generation import make_affine_matrix
+
+        ig, sd, bf, rs_, nz, gm = (self.intensity_generator, self.spatial_deform, self.biasfield, self.resampled, self.noise,
+                                   self.gamma)
+        rs = np.random.random_sample
+        # ---- seeds + intensities (rand_gmm.py:81-87, :120-148)
+        picks = np.random.randint(ig.min_subclusters, ig.max_subclusters + 1, size=ig.meta_labels).tolist()
+        m2s = {m + 1: picks[m] for m in range(ig.meta_labels)}
+        nlabels = max(ig.seed_labels) + 1
+        u2 = torch.rand(2 * nlabels, dtype=torch.float32).numpy()
+        mus = np.float32(25) + np.float32(200) * u2[:nlabels]
+        sigmas = np.float32(5) + np.float32(20) * u2[nlabels:]
+        if ig.generation_classes != ig.seed_labels:
+            if ig._idx is None:
+                ig._idx = (np.asarray(ig.generation_classes), np.asarray(ig.seed_labels))
+            z = torch.randn(len(ig.seed_labels), dtype=torch.float32).numpy()
+            tied = mus[ig._idx[0]] + np.float32(25) * z
+            mus[ig._idx[1]] = np.minimum(np.maximum(tied, np.float32(0)), np.float32(225))
+        gmm_plan = GMMPlan(torch.from_numpy(mus), torch.from_numpy(sigmas), _rng.normal_field(shape, stream_id=1))
+        # ---- deformation (affine_nonrigid.py:140-145, :248-263, :284, :303-318)
+        dplan = DeformPlan()
+        if rs(1)[0] < sd.prob:
+            nl = bool(sd.nonlinear_transform)
+            u = rs(13 if nl else 11)  # flip, rot x3, shear x3, scale x3 [, nonlin scale, nonlin std], then the gamma gate
+            dplan.active = True
+            dplan.flip = bool(u[0] < sd.flip_prb)
+            shp, centre32, room64 = sd._shape_constants(tuple(shape)[0:3])
+            ul = u.tolist()  # Python floats: the same IEEE doubles, a tenth of the cost of 0-d / 3-element numpy arithmetic
+            mr2, mr, ms2, ms, mc2, mc, pi = 2 * sd.max_rotation, sd.max_rotation, 2 * sd.max_shear, sd.max_shear, 2 * sd.max_scaling, sd.max_scaling, np.pi
+            rot = np.array([(mr2 * ul[1] - mr) / 180.0 * pi, (mr2 * ul[2] - mr) / 180.0 * pi, (mr2 * ul[3] - mr) / 180.0 * pi])
+            shr = np.array([ms2 * ul[4] - ms, ms2 * ul[5] - ms, ms2 * ul[6] - ms])
+            scl = np.array([1 + (mc2 * ul[7] - mc), 1 + (mc2 * ul[8] - mc), 1 + (mc2 * ul[9] - mc)])
+            dplan.A = torch.from_numpy(make_affine_matrix(rot, shr, scl).astype(np.float32))
+            ut = torch.rand(3, dtype=torch.float64).tolist()  # float64 draw, always consumed
+            c32, r64 = sd._shape_lists(tuple(shape)[0:3])
+            centre = np.array([c32[0] + (2 * (r64[0] * ut[0]) - r64[0]), c32[1] + (2 * (r64[1] * ut[1]) - r64[1]),
+                               c32[2] + (2 * (r64[2] * ut[2]) - r64[2])])
+            dplan.c2 = torch.from_numpy(centre)
+            nr_params = {}
+            if nl:
+                scale = sd.nonlin_scale_min + u[10:11] * (sd.nonlin_scale_max - sd.nonlin_scale_min)
+                sc = float(scale[0])
+                small = [int(round(sc * float(shp[0]))), int(round(sc * float(shp[1]))), int(round(sc * float(shp[2])))]
+                std = sd.nonlin_std_max * ul[11]
+                dplan.field_small = std * torch.randn([*small, 3], dtype=torch.float32)
+                nr_params = {"nonlin_scale": scale, "nonlin_std": std, "size_F_small": small}
+            dplan.params = {"affine": {"rotations": rot, "shears": shr, "scalings": scl}, "non_rigid": nr_params,
+                            "flip": dplan.flip}
+            gate_gamma = u[-1]
+        else:
+            gate_gamma = rs(1)[0]
+        # ---- gamma (synthseg.py:263-268)
+        g = np.exp(gm.gamma_std * np.random.randn(1)[0]) if gate_gamma < gm.prob else None
+        # ---- bias field (synthseg.py:157-176), then the resampling gate
+        bplan = BiasPlan()
+        if rs(1)[0] < bf.prob:
+            u = rs(3)
+            bplan.active = True
+            scale = bf.scale_min + u[0:1] * (bf.scale_max - bf.scale_min)
+            sc = float(scale[0])
+            size = [max(int(round(sc * float(shape[0]))), 1), max(int(round(sc * float(shape[1]))), 1),
+                    max(int(round(sc * float(shape[2]))), 1)]
+            std = bf.std_min + (bf.std_max - bf.std_min) * u[1:2]
+            std32 = np.asarray(std, dtype=np.float32)
+            bplan.grid = torch.from_numpy(std32 * torch.randn(size, dtype=torch.float32).numpy())
+            bplan.params = {"bf_scale": scale, "bf_std": std, "bf_size": size}
+            gate_res = u[2]
+        else:
+            gate_res = rs(1)[0]
+        # ---- resampling (synthseg.py:63-80), then the noise gate
+        rplan = ResamplePlan()
+        res = self.__dict__.get("_res64")
+        if res is None:
+            res = self._res64 = np.array(self.resolution)
+        if gate_res < rs_.prob:
+            u = rs(3)
+            rplan.active = True
+            # np.random.uniform(lo, hi) == lo + (hi - lo) * random_sample()
+            spacing = np.array([1.0, 1.0, 1.0]) * (rs_.min_resolution + (rs_.max_resolution - rs_.min_resolution) * float(u[0]))
+            rplan.spacing = spacing
+            rplan.stds, rplan.new_size, rplan.factors, rplan.tabs = T.resample_plan(tuple(shape), res, spacing, float(u[1]))
+            gate_noise = u[2]
+        else:
+            gate_noise = rs(1)[0]
+        # ---- noise (synthseg.py:218-232)
+        nplan = NoisePlan()
+        if gate_noise < nz.prob:
+            nplan.active = True
+            std = nz.std_min + (nz.std_max - nz.std_min) * rs(1)
+            nplan.std32 = float(np.asarray(std, dtype=np.float32).reshape(-1)[0])
+            nplan.field = _rng.normal_field(tuple(rplan.new_size if rplan.active else shape), stream_id=2)
+        return m2s, gmm_plan, dplan, g, bplan, rplan, nplan
 
     # A sample goes through three host phases so that B samples can share one parameter upload and one native call:
     #   _prepare : every random draw, in the reference's order, and the small arrays added to the arena   (no device work)
@@ -383,23 +649,32 @@ class FetalSynthGen:
         c = _Ctx()
         c.arena, c.image, c.segmentation, c.segmentation_u8, c.genparams = arena, image, segmentation, segmentation_u8, genparams
         c.labels, c.label_parts, c.gmm_plan, c.selected_seeds = None, None, None, {}
+        drawn = False
         if seeds is not None:
             gs = genparams.get("selected_seeds", {})
-            if hasattr(seeds, "parts") and ig.meta_labels <= 4:  # device-resident SeedBank
+            if hasattr(seeds, "parts") and ig.meta_labels <= 4 and not genparams and not _SLOW_PLAN:
+                # the common case (device-resident SeedBank, nothing fixed by the caller): every draw of the sample in bulk
+                shape = tuple(seeds.shape)
+                m2s, c.gmm_plan, c.dplan, c.g, c.bplan, c.rplan, c.nplan = self._draw_all_fast(shape)
+                c.label_parts, c.selected_seeds = seeds.parts(m2s), {"mlabel2subclusters": m2s}
+                drawn = True
+            elif hasattr(seeds, "parts") and ig.meta_labels <= 4:  # device-resident SeedBank
                 m2s = ig.draw_subclusters(gs)
                 c.label_parts, c.selected_seeds = seeds.parts(m2s), {"mlabel2subclusters": m2s}
                 shape = tuple(c.label_parts[0].shape)
             else:
                 c.labels, c.selected_seeds = ig.load_seeds(seeds=seeds, genparams=gs)
                 shape = tuple(c.labels.shape)
-            c.gmm_plan = ig.plan_intensities(shape, genparams.get("seed_intensities", {}))
+            if not drawn:
+                c.gmm_plan = ig.plan_intensities(shape, genparams.get("seed_intensities", {}))
         else:
             if image is None:
                 raise ValueError(
                     "If no seeds are passed, an image must be loaded to be used as intensity prior!")
             shape = tuple(image.shape)
         c.shape = shape
-        c.dplan, c.g, c.bplan, c.rplan, c.nplan = self._draw_plans(shape, genparams)
+        if not drawn:
+            c.dplan, c.g, c.bplan, c.rplan, c.nplan = self._draw_plans(shape, genparams)
         dplan, bplan, rplan = c.dplan, c.bplan, c.rplan
 
         c.sb = sd.make_spec(dplan, shape, flip_in_kernel=True, arena=arena) if dplan.active else None
@@ -439,6 +714,10 @@ class FetalSynthGen:
             arena = T.Arena()
             c = self._prepare(image, segmentation, seeds, genparams, arena, segmentation_u8)
             arena.upload(self.device)
+            if self._native_ok(c) and not _SLOW_PLAN:
+                native = self._run_native_fast(c, scale01)
+                if native is not None:
+                    return native[0], native[1], None, self._synth_params(c, {})
             self._resolve(c)
             if self._native_ok(c):
                 native = self._run_native(c, scale01)

@@ -102,6 +102,7 @@ class DeviceTables:
         self.lengths = tuple(len(t) for t in tabs)
         self._dev = [_device_table(t, device) for t in tabs]
         self.ptrs = tuple(C.c_void_p(d.data_ptr()) for d in self._dev)  # the device copies never move
+        self.ptrs_i = tuple(int(d.data_ptr()) for d in self._dev)        # the same as plain integers (flat plan arrays)
 
 
 _DT_CACHE: dict = {}  # (id(host table list), device) -> (DeviceTables, the list kept alive)

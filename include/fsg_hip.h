@@ -435,6 +435,24 @@ int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
  * behind the upload of every plan's parameters and waits for them afterwards; per sample the work is exactly
  * fsg_sample_run's (reference: B consecutive FetalSynthGen.sample calls, generator/model.py:231-276; the reference's
  * DataLoader collates B such samples, data/datasets.py:310-325, docs/datasets.md:4-6). */
+/* The plan from two flat arrays (one FFI call instead of a field-by-field fill): iv[FSG_PLAN_I_*] integers and pointers as
+ * int64, fv[FSG_PLAN_F_*] doubles that hold float32 values exactly, taps = 3 x FSG_PLAN_TAPS_STRIDE floats (row a = the
+ * blur taps of axis a, FSG_PLAN_I_BLUR_NTAPS + a of them).  fsg_sample_pack_run = pack + fsg_sample_run. */
+enum {
+  FSG_PLAN_I_SHAPE = 0, FSG_PLAN_I_LABEL_PARTS = 3, FSG_PLAN_I_MUS = 7, FSG_PLAN_I_SIGMAS = 8, FSG_PLAN_I_NTAB = 9,
+  FSG_PLAN_I_GMM_NOISE = 10, FSG_PLAN_I_GMM_SEED = 11, FSG_PLAN_I_GMM_STREAM = 12, FSG_PLAN_I_DEFORM_ACTIVE = 13,
+  FSG_PLAN_I_FLIP = 14, FSG_PLAN_I_FIELD_DIMS = 15, FSG_PLAN_I_FIELD = 18, FSG_PLAN_I_FIELD_TABS = 19, FSG_PLAN_I_SEG_IN = 22,
+  FSG_PLAN_I_SEG_OUT = 23, FSG_PLAN_I_SEG_IN_U8 = 24, FSG_PLAN_I_BIAS_DIMS = 25, FSG_PLAN_I_BIAS = 28, FSG_PLAN_I_BIAS_TABS = 29,
+  FSG_PLAN_I_RESAMPLE_ACTIVE = 32, FSG_PLAN_I_LOW_SHAPE = 33, FSG_PLAN_I_RS_TABS = 36, FSG_PLAN_I_BACK_TABS = 39,
+  FSG_PLAN_I_BLUR_NTAPS = 42, FSG_PLAN_I_NOISE_MODE = 45, FSG_PLAN_I_NOISE = 46, FSG_PLAN_I_NOISE_SEED = 47,
+  FSG_PLAN_I_NOISE_STREAM = 48, FSG_PLAN_I_SCALE01 = 49, FSG_PLAN_I_WS0 = 50, FSG_PLAN_I_WS1 = 51, FSG_PLAN_I_WS_LOW = 52,
+  FSG_PLAN_I_WS_ROWS = 53, FSG_PLAN_I_ROW_STRIDE = 54, FSG_PLAN_I_MM8 = 55, FSG_PLAN_I_MM8_PRESET = 56, FSG_PLAN_I_OUT = 57,
+  FSG_PLAN_I_EV_BEGIN = 58, FSG_PLAN_I_EV_END = 59, FSG_PLAN_I_MM_SLOTS = 60, FSG_PLAN_I_MM_NSLOTS = 61, FSG_PLAN_I_COUNT = 62
+};
+enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_GAMMA = 15, FSG_PLAN_F_NOISE_STD = 16, FSG_PLAN_F_COUNT = 17 };
+#define FSG_PLAN_TAPS_STRIDE 132
+int fsg_sample_plan_pack(fsg_sample_plan* plan, const int64_t* iv, int niv, const double* fv, int nfv, const float* taps);
+int fsg_sample_pack_run(const int64_t* iv, int niv, const double* fv, int nfv, const float* taps, void* stream);
 int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams);
 /* float32 -> float16 (round to nearest even) copy of a volume: the optional half-precision image of the output side. */
 int fsg_cast_f32_to_f16(const float* x, size_t n, void* out_f16, void* stream);

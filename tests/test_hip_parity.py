@@ -1190,6 +1190,67 @@ def test_prefetching_stream_batched_and_half_precision(K, tmp_path):
     assert torch.equal(K.cast_f16(x), x.to(torch.float16))
 
 
+@pytest.mark.parametrize("prob", [1.0, 0.5])
+def test_fast_plan_equals_field_by_field_plan(K, prob):
+    """The per-sample plan built as two flat arrays + fsg_sample_plan_pack (what `_pipeline` uses) against the plan filled
+    field by field through ctypes: byte-identical structs for random samples (gates on and off, reference and device RNG),
+    and identical outputs from the two paths."""
+    import ctypes as C
+
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd import rng as _rng
+    from fetalsyngen_amd import tables as T
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.generator import model as M
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (40, 48, 56)
+    seg, seeds = make_seed_volumes(shape, 2)
+    bank, segd = SeedBank(seeds, DEV), dev(seg)
+    lib = _lib.load()
+    for mode in ("device", "reference"):
+        gen = make_generator(shape, DEV, rng=mode, prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.03, 0.12))
+        for seed in range(6):
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            with _rng.use(gen.rng):
+                arena = T.Arena()
+                c = gen._prepare(None, segd, bank, {}, arena)
+                arena.upload(DEV)
+                gen._resolve(c)
+                gen._native_operands(c)
+                ws = gen._workspace(c.shape, gen._rows_needed(c))
+                out = torch.empty(c.shape, dtype=torch.float32, device=DEV)
+                seg_out = torch.empty_like(c.seg)
+                slow = _lib.SamplePlan()
+                assert gen._fill_native_plan(slow, c, True, ws, out, seg_out)
+                assert gen._fast_operands(c) and gen._flat_plan(c, True, out, seg_out if c.dplan.active else c.seg, ws)
+                fb = gen._flat
+                fast = _lib.SamplePlan()
+                _lib.check(lib.fsg_sample_plan_pack(C.byref(fast), fb["ivp"], gen._I["COUNT"], fb["fvp"], 17, fb["tbp"]), "pack")
+                if not c.dplan.active:  # the field-by-field plan leaves seg pointers unset without a deformation; so does pack
+                    assert fast.seg_in is None and fast.seg_out is None
+                if mode == "reference":  # host-tape noise is uploaded per plan: fresh device tensors, so the pointers differ
+                    for pl in (slow, fast):
+                        assert pl.gmm_noise and (pl.noise or not c.nplan.active)
+                        pl.gmm_noise, pl.noise = None, None
+                a, b = bytes(slow), bytes(fast)
+                assert a == b, [i for i in range(len(a)) if a[i] != b[i]][:16]
+    # and end to end: both paths give the same sample
+    gen = make_generator(shape, DEV, rng="device", prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.03, 0.12))
+    res = {}
+    for slow_plan in (False, True):
+        M._SLOW_PLAN = slow_plan
+        try:
+            np.random.seed(3)
+            torch.manual_seed(3)
+            res[slow_plan] = [gen._pipeline(None, segd, bank, {}, scale01=True)[:2] for _ in range(4)]
+        finally:
+            M._SLOW_PLAN = False
+    for (o1, l1), (o2, l2) in zip(res[False], res[True]):
+        assert torch.equal(o1, o2) and torch.equal(l1, l2)
+
+
 def test_workspace_eviction_across_streams(K):
     """More (shape, stream) keys than `FetalSynthGen._ws` keeps (4): samples interleaved over 6 streams evict
     each other's scratch volumes while kernels are still in flight; every result must equal the same sample

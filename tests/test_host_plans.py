@@ -181,3 +181,54 @@ def test_load_seeds_sums_meta_labels():
     lab2, sel2 = ig.load_seeds(seeds, genparams={"mlabel2subclusters": {1: 2, 2: 2, 3: 2, 4: 2}})
     assert sel2["mlabel2subclusters"] == {1: 2, 2: 2, 3: 2, 4: 2}
     assert set(np.unique(lab2.numpy())) <= {0, 10, 11, 20, 21, 30, 31, 40, 41}
+
+
+@pytest.mark.parametrize("mode", ["device", "reference"])
+@pytest.mark.parametrize("prob", [1.0, 0.9, 0.5, 0.0])
+def test_bulk_draws_equal_per_stage_plans(prob, mode):
+    """`FetalSynthGen._draw_all_fast` (draws between two gates fetched with one numpy call, torch.rand(2n) for the two GMM
+    tables) against the per-stage plan() functions: every drawn quantity identical, both global generators left at the same
+    position -- for many seeds, gates passing and failing, nonlinear field on and off, shape != size (random shift)."""
+    from tests.util_cases import make_generator
+
+    def same(a, b):
+        if a is None or b is None:
+            return a is None and b is None
+        if torch.is_tensor(a):
+            return torch.is_tensor(b) and a.dtype == b.dtype and torch.equal(a, b)
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+        if isinstance(a, dict):
+            return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (list, tuple)):
+            return type(a) is type(b) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return type(a) is type(b) and a == b
+
+    for shape, size, nonlin in (((32, 32, 32), None, True), ((40, 36, 28), (32, 32, 24), True), ((24, 24, 24), None, False)):
+        gen = make_generator(shape, "cuda:0", prob=prob, nonlin_scale=(0.1, 0.3), bf_scale=(0.05, 0.2), size=size, rng=mode)
+        gen.spatial_deform.nonlinear_transform = nonlin
+        for seed in range(25):
+            outs = []
+            for fast in (False, True):
+                np.random.seed(seed)
+                torch.manual_seed(seed)
+                plans = gen.plan_only(shape, fast=fast)
+                outs.append((plans, np.random.rand(3), torch.rand(3)))
+            (pa, na, ta), (pb, nb, tb) = outs
+            assert np.array_equal(na, nb) and torch.equal(ta, tb), (shape, seed)
+            m2s_a, gmm_a, d_a, g_a, b_a, r_a, n_a = pa
+            m2s_b, gmm_b, d_b, g_b, b_b, r_b, n_b = pb
+            assert m2s_a == m2s_b and all(type(v) is int for v in m2s_b.values())
+            assert same(gmm_a.mus, gmm_b.mus) and same(gmm_a.sigmas, gmm_b.sigmas)
+            assert (gmm_a.field.seed, gmm_a.field.stream_id) == (gmm_b.field.seed, gmm_b.field.stream_id)
+            assert same(gmm_a.field.host, gmm_b.field.host)
+            assert d_a.active == d_b.active and d_a.flip == d_b.flip and same(d_a.A, d_b.A) and same(d_a.c2, d_b.c2)
+            assert same(d_a.field_small, d_b.field_small) and same(d_a.params, d_b.params)
+            assert same(g_a, g_b)
+            assert b_a.active == b_b.active and same(b_a.grid, b_b.grid) and same(b_a.params, b_b.params)
+            assert r_a.active == r_b.active and same(r_a.spacing, r_b.spacing) and same(r_a.stds, r_b.stds)
+            assert r_a.new_size == r_b.new_size and same(r_a.factors, r_b.factors)
+            assert (r_a.tabs is None and r_b.tabs is None) or all(x is y for x, y in zip(r_a.tabs, r_b.tabs))
+            assert n_a.active == n_b.active and n_a.std32 == n_b.std32
+            if n_a.active:
+                assert (n_a.field.seed, n_a.field.shape) == (n_b.field.seed, n_b.field.shape) and same(n_a.field.host, n_b.field.host)
