@@ -431,6 +431,8 @@ def run(args, rank, world, local):
 
     gen = build_generator(shape, device, args.rng)
     gen.prewarm()  # static per-axis tables of this configuration -> device (outside the timed region)
+    if not os.environ.get("FSG_BENCH_NO_RESERVE"):
+        gen.reserve(shape, samples_in_flight=12)  # memory pool sized for the samples the host keeps in flight
 
     result_extra = {}
     if rank == 0 and not args.no_microbench:

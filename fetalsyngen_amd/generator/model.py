@@ -115,6 +115,22 @@ class FetalSynthGen:
                     n += 1
         return n
 
+    def reserve(self, shape=None, samples_in_flight: int = 8) -> int:
+        """Pre-size the device memory pool for `samples_in_flight` samples whose outputs are alive at once (the host runs
+        several samples ahead of the GPU, and a consumer may hold a few): allocates and releases that many image / label
+        volumes and parameter arenas through torch's caching allocator, so that the first samples do not pay for
+        hipMalloc calls (0.2-1 ms each) in the middle of the launch stream.  Returns the bytes reserved."""
+        shape = tuple(int(v) for v in (shape or self.shape))
+        dev = torch.device(self.device)
+        hold = []
+        for _ in range(int(samples_in_flight)):
+            hold.append(torch.empty(shape, dtype=torch.float32, device=dev))   # image
+            hold.append(torch.empty(shape, dtype=torch.float32, device=dev))   # labels
+            hold.append(torch.empty(1 << 16, dtype=torch.uint8, device=dev))   # parameter arena
+        total = sum(t.numel() * t.element_size() for t in hold)
+        del hold
+        return total
+
     # ---- native fused path -------------------------------------------------------------------------
     def _workspace(self, shape, need_rows):
         """Per (shape, stream) scratch volumes, reused by consecutive samples on that stream.
