@@ -502,6 +502,31 @@ def test_e2e_device_rng_fullsize_vs_oracle(K):
     assert o.min() == 0.0 and o.max() == 1.0
 
 
+def test_e2e_reference_rng_fullsize_vs_oracle(K):
+    """BASELINE config 2 as stated: a single 256^3 volume, full path, SEED-MATCHED against the CPU path -- `rng="reference"`
+    (both large noise fields drawn by torch's CPU generator at the reference's points of the draw order and uploaded), the
+    oracle under the same numpy / torch seeds: labels bit-exact, [0,1] image within 2e-5, both generators left at the same
+    position."""
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (256, 256, 256)
+    seg, seeds = make_seed_volumes(shape, 1)
+    gen = make_generator(shape, DEV, rng="reference")
+    np.random.seed(11)
+    torch.manual_seed(11)
+    out, seg_d, _img, params = gen._pipeline(None, t(seg), seeds, {}, scale01=True)
+    torch.cuda.synchronize()
+    tail_product = (np.random.rand(), float(torch.rand(1)))
+    np.random.seed(11)
+    torch.manual_seed(11)
+    r = O.run_sample(O.Config(shape, prob=1.0), t(seg), seeds)
+    tail_oracle = (np.random.rand(), float(torch.rand(1)))
+    assert tail_product == tail_oracle
+    assert np.array_equal(host(params["seed_intensities"]["mus"]), r["params"]["mus"].numpy())
+    assert np.array_equal(host(seg_d).astype(np.uint8), r["seg"].numpy().astype(np.uint8)), "labels bit-exact at 256^3"
+    np.testing.assert_allclose(host(out), r["scaled"].numpy(), rtol=0, atol=2e-5)
+
+
 def test_dataset_contract_and_determinism(K, tmp_path):
     """FetalSynthDataset on a tiny BIDS tree written by the test: output dict contract, CPU tensors,
     int64 labels, params schema; same seeds => identical sample; cache on/off agree."""
