@@ -1501,7 +1501,7 @@ int fsg_warp_set_variant(int variant) {
   const int prev = g_warp_variant;
   g_lean_ablate = 0;
   if (variant == 8 || variant == 9) { g_warp_variant = 0; g_lean_pace = 1; g_lean_ablate = variant - 7; }
-  if (variant >= 0 && variant <= 4) { g_warp_variant = variant; g_lean_pace = 1; }
+  if (variant >= 0 && variant <= 4) { g_warp_variant = variant; g_lean_pace = -1; }
   if (variant >= 5 && variant <= 7) { g_warp_variant = 0; g_lean_pace = variant == 5 ? 0 : (variant == 6 ? 2 : 1); }
   return prev;
 }

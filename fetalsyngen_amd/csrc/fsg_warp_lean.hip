@@ -25,7 +25,7 @@
 #include "fsg_common.h"
 
 int g_lean_ablate = 0;  // 1 / 2: the diagnostic kernels (ABL), never set by the product
-int g_lean_pace = 1;  // lockstep barrier: 1 = every step, 2 = every second step, 0 = none (fsg_warp_set_variant 5..7)
+int g_lean_pace = -1;  // lockstep barrier: 1 = every step, 2 = every second step, 0 = none; -1 = chosen per launch (fsg_warp_set_variant 5..7 force one)
 
 namespace {
 
@@ -119,49 +119,59 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
 
   // One step of one lane, split in two so that the gathers of step s+1 are in flight while step s is blended:
   //   issue(kb, P)  -- sampling position of voxel (i, j, kb + kz), the label gather and the four 8-byte gathers
-  //   finish(P)     -- weights, blend, epilogue, stores
+  //   finish(P)     -- blend, epilogue, stores
+  // The arithmetic is written on register PAIRS (f2v) wherever two results share their operation sequence -- (y, z) of
+  // the affine map, the two z-neighbours of every blend -- so that it lands on v_pk_mul_f32 / v_pk_add_f32 with the pairs
+  // where the loads put them (no v_mov / v_pk_mov shuffles); each half is the reference's own operation order.
   struct Pend {
     f2v p00, p10, p01, p11;
-    float x, y, z;
+    float bx;
+    f2v byz;
+    bool ok;
     ST lab;
   };
-  auto offset_of = [&](float x, float y, float z) {  // byte offset of the lower corner of the 2x2x2 neighbourhood
-    const int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
-    return (unsigned)(base + __mul24(x0, sxs) + __mul24(y0, sy) + z0) * 4u;
-  };
+  const f2v A_x = {D.A[3], D.A[6]}, A_y = {D.A[4], D.A[7]}, A_z = {D.A[5], D.A[8]}, c2_yz = {D.c2[1], D.c2[2]};
+  const f2v m_yz = {m.my, m.mz}, pb_xy = {pxb, pyb};
+  const float hz1 = hz - 1.f;
   auto issue = [&](int kb, Pend& P) {
     const int k = min(kb + kz, D.n2 - 1);
-    float px = pxb, py = pyb, pz = (float)k - D.cen[2];
+    f2v pxy = pb_xy;
+    float pz = (float)k - D.cen[2];
     if (has_field && ABL != 2) {
       const int4 c = s_tz[k];
       const float wl = __builtin_bit_cast(float, c.z), wh = __builtin_bit_cast(float, c.w);
       const float4 a = sf[c.x], b = sf[c.y];
-      px = px + (wl * a.x + wh * b.x);
-      py = py + (wl * a.y + wh * b.y);
-      pz = pz + (wl * a.z + wh * b.z);
+      pxy = pxy + (f2v{a.x, a.y} * wl + f2v{b.x, b.y} * wh);
+      float tz = wl * a.z;
+      asm("" : "+v"(tz));  // keeps this product scalar: a packed form would first move (a.z, b.z) into a register pair
+      pz = pz + (tz + wh * b.z);
     }
-    float x = D.A[0] * px + D.A[1] * py + D.A[2] * pz + D.c2[0];
-    float y = D.A[3] * px + D.A[4] * py + D.A[5] * pz + D.c2[1];
-    float z = D.A[6] * px + D.A[7] * py + D.A[8] * pz + D.c2[2];
-    if (ABL == 2) { x = (float)i + 0.25f; y = (float)j + 0.25f; z = (float)k * 0.98f + 0.3f; }
+    float x = D.A[0] * pxy.x + D.A[1] * pxy.y + D.A[2] * pz + D.c2[0];
+    f2v yz = A_x * pxy.x + A_y * pxy.y + A_z * pz + c2_yz;
+    if (ABL == 2) { x = (float)i + 0.25f; yz.x = (float)j + 0.25f; yz.y = (float)k * 0.98f + 0.3f; }
     x = __builtin_amdgcn_fmed3f(x, 0.f, hx) - m.mx;
-    y = __builtin_amdgcn_fmed3f(y, 0.f, hy) - m.my;
-    z = __builtin_amdgcn_fmed3f(z, 0.f, hz) - m.mz;
-    P.x = x; P.y = y; P.z = z;
+    yz = f2v{__builtin_amdgcn_fmed3f(yz.x, 0.f, hy), __builtin_amdgcn_fmed3f(yz.y, 0.f, hz)} - m_yz;
     const bool mem = ABL != 1 || x == 1.2345e30f;  // ABL 1: never true, decided per lane at run time
     P.lab = 0;
     if (HAS_NN) {
-      const int xi = (int)rintf(x), yi = (int)rintf(y), zi = (int)rintf(z);  // round half to even; in range by construction
-      const unsigned e = (unsigned)(base + __mul24(xi, sxs) + __mul24(yi, sy) + zi);
+      const int xi = (int)rintf(x), yi = (int)rintf(yz.x), zi = (int)rintf(yz.y);  // round half to even; in range by construction
+      const unsigned e = (unsigned)(__mul24(xi, sxs) + (__mul24(yi, sy) + (zi + base)));
       if (ABL != 1) P.lab = lean_load_label<ST>(r_nn, e);
       else if (mem) P.lab = lean_load_label<ST>(r_nn, e);
       else P.lab = (ST)(e & 7u);
     }
     if (HAS_LIN) {
+      P.ok = (x > 0.f) && (yz.x > 0.f) && (yz.y > 0.f);
+      // z exactly on the last column: the pair (z0, z0 + 1) would leave the row, so the pair one to the left is read with
+      // weights (0, 1) -- the reference's (1, 0) on a neighbour clamped onto the column itself gives the same value
+      const float fx = floorf(x);
+      const f2v fyz = {floorf(yz.x), __builtin_amdgcn_fmed3f(floorf(yz.y), -1.f, hz1)};
+      P.bx = x - fx;
+      P.byz = yz - fyz;
       // unconditional: a voxel that samples outside the volume is clamped onto a face, its (unused) reads are in range and
       // mostly hit the lines its neighbours fetch; a predicated gather would make the number of loads in flight unknown to
       // the compiler, which then waits for ALL of them (vmcnt(0)) -- including the next step's -- before every blend
-      const unsigned o = offset_of(x, y, z);
+      const unsigned o = (unsigned)(__mul24((int)fx, sxs) + (__mul24((int)fyz.x, sy) + ((int)fyz.y + base))) * 4u;
       if (ABL != 1 || mem) {
         P.p00 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o, 0, 0));
         P.p10 = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(r_lin, o + (unsigned)dxb, 0, 0));
@@ -178,27 +188,14 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
     const bool live = live_row && kk < D.n2;
     const unsigned oelem = orow + (unsigned)kk;
     if (HAS_LIN) {
-      const float x = P.x, y = P.y, z = P.z;
-      const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f);
-      const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-      const float bx = x - fx, by = y - fy, bz = z - fz;
-      const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
-      f2v p00 = P.p00, p10 = P.p10, p01 = P.p01, p11 = P.p11;
-      if (ok && (int)fz >= D.n2 - 1) {  // rare (z exactly on the last column): single-element reads, upper neighbour unused
-        const unsigned o = offset_of(x, y, z);
-        p00.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o, 0, 0));
-        p10.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)dxb, 0, 0));
-        p01.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)oyb, 0, 0));
-        p11.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_lin, o + (unsigned)(dxb + oyb), 0, 0));
-        p00.y = p00.x; p10.y = p10.x; p01.y = p01.x; p11.y = p11.x;
-      }
-      const float c00 = p00.x * ax + p10.x * bx;
-      const float c01 = p00.y * ax + p10.y * bx;
-      const float c10 = p01.x * ax + p11.x * bx;
-      const float c11 = p01.y * ax + p11.y * bx;
-      const float c0 = c00 * ay + c10 * by;
-      const float c1 = c01 * ay + c11 * by;
-      float v = ok ? (c0 * az + c1 * bz) : 0.f;
+      const float bx = P.bx, ax = 1.f - bx;
+      const f2v byz = P.byz, ayz = 1.f - byz;
+      const f2v cx0 = P.p00 * ax + P.p10 * bx;      // (c00, c01): the two z-neighbours at y0
+      const f2v cx1 = P.p01 * ax + P.p11 * bx;      // (c10, c11): at y0 + 1
+      const f2v cy = cx0 * ayz.x + cx1 * byz.x;     // (c0, c1)
+      float c0z = cy.x * ayz.y;
+      asm("" : "+v"(c0z));  // scalar on purpose, as above: (az, bz) straddles the (ay, az) / (by, bz) pairs
+      float v = P.ok ? (c0z + cy.y * byz.y) : 0.f;
       if (E.gamma > 0.f) {
         // 300*(v/300)^g.  FAST: 300 * 2^(g*(log2 v - log2 300)) on v_log_f32 / v_exp_f32; else OCML powf and an IEEE division
         if (FAST) v = 300.0f * __builtin_amdgcn_exp2f(E.gamma * (__builtin_amdgcn_logf(v) - 8.2288186904958804f));
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const 
       if (live && (ABL != 1 || v == 1.2345e30f))
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_olin, oelem * 4u, 0, 0);
     }
-    if (HAS_NN && live && (ABL != 1 || P.x == 1.2345e30f)) lean_store_label(r_onn, oelem, (DT)P.lab);
+    if (HAS_NN && live && (ABL != 1 || P.bx == 1.2345e30f)) lean_store_label(r_onn, oelem, (DT)P.lab);
   };
 
   // the barrier only paces the 16 waves (same z slab -> the brick's source block is what L1 holds); nothing is
@@ -238,16 +235,22 @@ int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const fl
   constexpr int KZ = 32, WI = 8;
   constexpr int PI = WI, PJ = (16 / WI) * (64 / KZ);
   const dim3 grid((unsigned)(((D.n0 + PI - 1) / PI) * ((D.n1 + PJ - 1) / PJ))), block(1024);
+  // Pacing.  The barrier keeps the 16 waves on one z slab so that L1 holds the source block they share.  With a small
+  // slope of the source position along the output row (|dx/dk|, |dy/dk| -- the affine's third column) a slab's block is
+  // small and stays resident across two steps, and a barrier every second step is 4-5 us faster at 256^3; beyond
+  // ~16 degrees the every-step barrier wins (gpurun_out r4d, profiles/r02_f_warp_pace.txt).
+  const float slope = fmaxf(fabsf(D.A[2]), fabsf(D.A[5]));
+  const int pace = g_lean_pace >= 0 ? g_lean_pace : (slope < 0.27f ? 2 : 1);
 #define FSG_LEAN(L, N, F) \
   hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E, \
-                     g_lean_pace)
+                     pace)
   if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {  // diagnostic builds (tools/warp_ab.sh)
     if (g_lean_ablate == 1)
       hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 1>), grid, block, 0, st, D, mm6, src_lin, out_lin,
-                         src_nn, out_nn, E, g_lean_pace);
+                         src_nn, out_nn, E, pace);
     else
       hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 2>), grid, block, 0, st, D, mm6, src_lin, out_lin,
-                         src_nn, out_nn, E, g_lean_pace);
+                         src_nn, out_nn, E, pace);
     FSG_RETURN_LAUNCH();
   }
   if (src_lin && src_nn) { if (fast) FSG_LEAN(true, true, true); else FSG_LEAN(true, true, false); }

@@ -1,15 +1,8 @@
-mkdir -p gpurun_out/r3h
-bash tools/prof_bench.sh r3h > gpurun_out/r3h/prof.log 2>&1
-python bench.py > gpurun_out/r3h/bench_default.json 2> gpurun_out/r3h/bench_default.err; echo "default rc=$?"
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3h/bench_driver.json 2> gpurun_out/r3h/bench_driver.err; echo "driver rc=$?"
-FSG_BENCH_SHARE_GPU0=1 python bench.py --gpus 2 --steps 100 --warmup 10 --stream-volumes 400 > gpurun_out/r3h/bench_2rank.json 2> gpurun_out/r3h/bench_2rank.err; echo "2rank rc=$?"
-python tools/host_phases.py > gpurun_out/r3h/host_phases.txt 2>&1
+mkdir -p gpurun_out/r4f
+for s in 1 2 3; do python bench.py --no-cpu-baseline --no-sr --no-config3 --no-config5 --no-microbench --streams $s > gpurun_out/r4f/bench_s$s.json 2> gpurun_out/r4f/bench_s$s.err; echo "streams $s rc=$?"; done
 python - <<'PY'
 import json
-for f in ["bench_driver","bench_default","bench_2rank"]:
-    d=json.loads([l for l in open(f"gpurun_out/r3h/{f}.json") if l.startswith("{")][-1])
-    print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["us_per_launch"], d["roofline_step"]["frac"], d["n_gpus"])
-    print("   c3", d["config3"]["wall_ms"], d["config3"]["checksum"], "c5", {k:v["volumes_per_s"] for k,v in d["config5"].items() if isinstance(v, dict)})
-    if "cpu_baseline" in d: print("   cpu", d["cpu_baseline"]["value"], d.get("gpu_over_cpu"), d.get("gpu_over_reference_anchor"))
+for s in (1,2,3):
+    d=json.loads([l for l in open(f"gpurun_out/r4f/bench_s{s}.json") if l.startswith("{")][-1])
+    print(s, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["us_per_launch"], d["roofline_step"]["frac"])
 PY
-head -12 gpurun_out/r3h/kernel_stats.csv | cut -c1-150
