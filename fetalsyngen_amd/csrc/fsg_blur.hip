@@ -214,8 +214,13 @@ __global__ __launch_bounds__(256) void blur_yz_fused_kernel(const float4* __rest
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [YZ_ROWS][nz + 2 RP]
   const int inner4 = nz >> 2, pitch = nz + 2 * RP;
   const int tx = threadIdx.x, tyc = threadIdx.y;  // 64 x 4
-  const int y0 = blockIdx.x * YZ_ROWS;
-  const size_t plane4 = (size_t)blockIdx.y * ny * inner4;
+  // 1-D grid of (plane, y tile) pairs, every XCD given a contiguous range of them: the two tiles that share a y halo run on
+  // the same XCD one after the other, so the halo rows are served by its L2 instead of being read from HBM twice
+  const int tiles_y = (ny + YZ_ROWS - 1) / YZ_ROWS;
+  const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int bx = tile / tiles_y;
+  const int y0 = (tile - bx * tiles_y) * YZ_ROWS;
+  const size_t plane4 = (size_t)bx * ny * inner4;
   // zero halos of every row
   for (int e = tyc * 64 + tx; e < YZ_ROWS * (2 * RP / 4); e += 256) {
     const int r = e / (2 * RP / 4), h = e - r * (2 * RP / 4);
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void blur_yz_fused_kernel(const float4* __rest
     const int y = y0 + r;
     if (y >= ny) break;
     const float* row = lds + (size_t)r * pitch;
-    float4* d4 = reinterpret_cast<float4*>(dst + ((size_t)blockIdx.y * ny + y) * nz);
+    float4* d4 = reinterpret_cast<float4*>(dst + ((size_t)bx * ny + y) * nz);
     for (int q = lane; q < inner4; q += 64) {
       float win[4 + 2 * RP];
 #pragma unroll
@@ -281,7 +286,7 @@ template <int R>
 int launch_yz(const float* src, float* dst, int nx, int ny, int nz, const Taps& T, hipStream_t st) {
   constexpr int RP = (R + 3) & ~3;
   const size_t lds = (size_t)YZ_ROWS * (nz + 2 * RP) * sizeof(float);
-  dim3 grid((unsigned)((ny + YZ_ROWS - 1) / YZ_ROWS), (unsigned)nx), block(64, 4);
+  dim3 grid((unsigned)((ny + YZ_ROWS - 1) / YZ_ROWS) * (unsigned)nx), block(64, 4);
   hipLaunchKernelGGL(blur_yz_fused_kernel<R>, grid, block, lds, st, reinterpret_cast<const float4*>(src), dst, ny, nz, T);
   FSG_RETURN_LAUNCH();
 }

@@ -52,9 +52,16 @@ struct EpiZ {
 // thousand workgroups ending with a gated atomic on them cost 15-25 us (profiles/r02_b_zoom_experiments.txt); with S slots
 // on separate 64-byte lines a workgroup updates slot blockIdx % S and the readers reduce the S slots (<= 64: one wave load).
 __device__ __forceinline__ void zoom_mm_update(const EpiZ& E, float lo, float hi) {
-  const int slot = E.mm_shards > 1 ? (int)(blockIdx.x % (unsigned)E.mm_shards) * FSG_MM_SLOT_STRIDE : 0;
-  fsg_atomic_min_key(&E.mm_out[slot], lo);
-  fsg_atomic_max_key(&E.mm_out[slot + 1], hi);
+  if (E.mm_shards > 1) {
+    // sharded: two atomics WITHOUT a returned value and without the load that gates the single-pair form -- nothing the
+    // workgroup has to wait for, it retires as soon as they are issued; S slots keep the per-address rate low
+    int32_t* s = E.mm_out + (int)(blockIdx.x % (unsigned)E.mm_shards) * FSG_MM_SLOT_STRIDE;
+    (void)__hip_atomic_fetch_min(&s[0], fsg_f2key(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(&s[1], fsg_f2key(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  fsg_atomic_min_key(&E.mm_out[0], lo);
+  fsg_atomic_max_key(&E.mm_out[1], hi);
 }
 __device__ __forceinline__ void zoom_mm_read(const EpiZ& E, float& mn, float& mx) {
   if (E.mm_shards > 1) {
@@ -75,6 +82,31 @@ __device__ __forceinline__ void zoom_mm_read(const EpiZ& E, float& mn, float& mx
     mn = fsg_key2f(E.mm_in[0]);
     mx = fsg_key2f(E.mm_in[1]);
   }
+}
+
+// the same in two halves, so that the loads are in flight while the caller does other work (slab kernel: behind its x stage)
+__device__ __forceinline__ void zoom_mm_issue(const EpiZ& E, int& kmin, int& kmax) {
+  const int lane = threadIdx.x & 63;
+  kmin = 0x7FFFFFFF;
+  kmax = (int)0x80000000;
+  if (E.mm_shards > 1) {
+    if (lane < E.mm_shards) {
+      kmin = E.mm_in[lane * FSG_MM_SLOT_STRIDE];
+      kmax = E.mm_in[lane * FSG_MM_SLOT_STRIDE + 1];
+    }
+  } else {
+    kmin = E.mm_in[0];
+    kmax = E.mm_in[1];
+  }
+}
+__device__ __forceinline__ void zoom_mm_finish(int kmin, int kmax, float& mn, float& mx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o, FSG_WAVE));
+    kmax = max(kmax, __shfl_xor(kmax, o, FSG_WAVE));
+  }
+  mn = fsg_key2f(__builtin_amdgcn_readfirstlane(kmin));
+  mx = fsg_key2f(__builtin_amdgcn_readfirstlane(kmax));
 }
 
 template <int EPI>
@@ -562,13 +594,8 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
   float lo = INFINITY, hi = -INFINITY;
   float mnq = 0.f, den = 1.f, mx = 1.f;
-  if (EPI == EPI_NORM) {
-    float mn;
-    zoom_mm_read(E, mn, mx);
-    mnq = mn / mx;
-    den = 1.0f - mnq;
-  }
-  const UniDiv ud = unidiv_make(mx);
+  int kmin_l = 0, kmax_l = 0;
+  if (EPI == EPI_NORM) zoom_mm_issue(E, kmin_l, kmax_l);  // consumed behind the x stage: the round trip hides under its loads
   // the z taps of this lane's four outputs: the same for every row of every tile
   int zlo[4], zhi[4];
   float zwl[4], zwh[4];
@@ -611,6 +638,13 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
     const int tot = nrows * Z.sz;  // the window rows are contiguous in the source: one linear, coalesced sweep
     for (int e = tid; e < tot; e += 256) xs[e] = fsg_mix(a.w_lo, pa[e], a.w_hi, pb[e]);
   }
+  if (EPI == EPI_NORM) {
+    float mn;
+    zoom_mm_finish(kmin_l, kmax_l, mn, mx);
+    mnq = mn / mx;
+    den = 1.0f - mnq;
+  }
+  const UniDiv ud = unidiv_make(mx);
   __syncthreads();
   auto row_tap = [&](int jj) {
     fsg_tap b = tb[jj];
@@ -749,7 +783,7 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   // measured at 256^3 (profiles/r02_b_zoom_experiments.txt): the slab kernel wins for the passes that store (K9b 28 vs 32.5 us);
   // the min/max pass ends every workgroup with two gated atomics, which cost the slab kernel's 4 096 workgroups more than the
   // row kernel's 2 048 (38 vs 31 us; 22 us with the atomics removed) whether or not the keys are sharded over slots
-  if (((!noise_epi && EPI != EPI_MINMAX) || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
+  if (((!noise_epi && (EPI != EPI_MINMAX || E.mm_shards > 1)) || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
       !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_TILE_ZOOM))) {
     int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;

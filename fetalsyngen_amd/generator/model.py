@@ -33,8 +33,9 @@ from .intensity.rand_gmm import ImageFromSeeds
 # [+inf x4 | -inf x4] as the order-preserving int32 keys of fsg_minmax_init (csrc/fsg_common.h: fsg_f2key)
 _MM8_INIT = np.array([0x7F800000] * 4 + [-2139095041] * 4, dtype=np.int32)
 _MM8_INIT.setflags(write=False)
-# K9's min / max keys sharded over 32 slots of 16 ints (include/fsg_hip.h: FSG_MM_SLOT_STRIDE), each {key(+inf), key(-inf), 0...}
-MM_NSLOTS, MM_SLOT_STRIDE = 32, 16
+# K9's min / max keys sharded over 64 slots of 16 ints (include/fsg_hip.h: FSG_MM_SLOT_STRIDE), each {key(+inf), key(-inf), 0...}:
+# the min/max pass ends every workgroup with two atomics nobody waits for (csrc/fsg_zoom.hip: zoom_mm_update)
+MM_NSLOTS, MM_SLOT_STRIDE = 64, 16
 _MM_SLOTS_INIT = np.zeros((MM_NSLOTS, MM_SLOT_STRIDE), dtype=np.int32)
 _MM_SLOTS_INIT[:, 0], _MM_SLOTS_INIT[:, 1] = 0x7F800000, -2139095041
 _MM_SLOTS_INIT.setflags(write=False)
@@ -42,6 +43,7 @@ _MM_SLOTS_INIT.setflags(write=False)
 
 import os as _os
 
+_NO_MM_SLOTS = _os.environ.get("FSG_NO_MM_SLOTS", "0") == "1"  # K9's keys as ONE pair (A/B runs)
 _SLOW_PLAN = _os.environ.get("FSG_SLOW_PLAN", "0") == "1"  # field-by-field ctypes plan instead of the flat arrays (cross-check)
 
 
@@ -214,6 +216,8 @@ class FetalSynthGen:
         if ws["rows"] is not None:
             p.ws_rows, p.row_stride = ws["rows"].data_ptr(), ws["stride"]
         p.mm8, p.mm8_preset = c.arena.ptr(c.mm_off), 1
+        if c.slots_off is not None:
+            p.mm_slots, p.mm_nslots = c.arena.ptr(c.slots_off), MM_NSLOTS
         p.out = out.data_ptr()
         return True
 
@@ -358,6 +362,8 @@ class FetalSynthGen:
         if ws["rows"] is not None:
             iv[I["WS_ROWS"]], iv[I["ROW_STRIDE"]] = ws["rows"].data_ptr(), ws["stride"]
         iv[I["MM8"]], iv[I["MM8_PRESET"]] = base + c.mm_off, 1
+        if c.slots_off is not None:
+            iv[I["MM_SLOTS"]], iv[I["MM_NSLOTS"]] = base + c.slots_off, MM_NSLOTS
         iv[I["OUT"]] = out.data_ptr()
         if events is not None:
             iv[I["EV_BEGIN"]], iv[I["EV_END"]] = events
@@ -705,6 +711,7 @@ class FetalSynthGen:
             bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
             c.back_tabs = K.device_tables_for(bt, dev)
         c.mm_off = arena.add(_MM8_INIT)  # the sample's min/max keys arrive initialised with its parameters
+        c.slots_off = arena.add(_MM_SLOTS_INIT) if rplan.active and not _NO_MM_SLOTS else None
         c.gm_off = None
         if c.gmm_plan is not None:
             c.gm_off = (arena.add(c.gmm_plan.mus.numpy()), arena.add(c.gmm_plan.sigmas.numpy()), c.gmm_plan.mus.numel())
