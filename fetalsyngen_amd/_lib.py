@@ -93,6 +93,11 @@ class SamplePlan(C.Structure):
         ("mm_slots", C.c_void_p),
         ("mm_nslots", C.c_int32),
         ("seg_in_u8", C.c_void_p),
+        ("arena_host", C.c_void_p),
+        ("arena_dev", C.c_void_p),
+        ("arena_bytes", C.c_uint64),
+        ("overlap", C.c_int32),
+        ("ws_seq", C.c_uint64),
     ]
 
 

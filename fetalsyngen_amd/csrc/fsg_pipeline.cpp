@@ -6,9 +6,46 @@
 // interpreter between launches costs as much as the kernels; semantics and results are those of calling the
 // entry points one by one (tests/test_hip_parity.py::test_native_pipeline_equals_stagewise).
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "../../include/fsg_hip.h"
 
 extern int g_tuning_flags;
+
+// ---- head of sample n+1 beside the tail of sample n (fsg_sample_plan::overlap) ---------------------------------------
+// Per launch stream: a side stream and two events.  `ev_free` is recorded on the launch stream at the point of a call after
+// which it no longer touches ws0 / ws_rows (after the blur, or after K7 when the blur's last pass lands in ws0); the next
+// call's upload + head wait for it on the side stream, the launch stream waits for `ev_head` before the margins and the warp.
+// The head is VALU-bound (Philox + Box-Muller), the resampling tail it runs beside is bound by LDS and latency.
+namespace {
+struct HeadOverlap {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_free = nullptr, ev_head = nullptr;
+  bool has_free = false;
+  uint64_t seq = 0;
+  const float* ws0 = nullptr;
+};
+std::mutex g_ho_mu;
+std::map<std::pair<int, hipStream_t>, HeadOverlap> g_ho;
+
+HeadOverlap* head_overlap_state(hipStream_t st, bool create) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ho_mu);
+  auto key = std::make_pair(dev, st);
+  auto it = g_ho.find(key);
+  if (it != g_ho.end()) return &it->second;
+  if (!create) return nullptr;
+  HeadOverlap h;
+  if (hipStreamCreateWithFlags(&h.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&h.ev_free, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h.ev_head, hipEventDisableTiming) != hipSuccess) {
+    return nullptr;
+  }
+  return &g_ho.emplace(key, h).first->second;  // std::map: the address stays valid
+}
+}  // namespace
 
 #define FSG_TRY(expr)        \
   do {                       \
@@ -27,19 +64,44 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
   bool head_done = false;
   fsg_deform dh = p->deform;
-  if (p->deform_active && p->mm8_preset && p->ws_rows && !(g_tuning_flags & FSG_TUNE_SPLIT_HEAD)) {
-    // K1 + per-row coarse values + six-face minimum in one launch (keys arrive initialised with the parameters)
-    const int need = 3 * dh.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
-    if (need > 0 && need <= p->row_stride) {
-      dh.rows = nullptr;
-      dh.row_stride = 0;
-      int rc = fsg_sample_head_f32(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
-                                   p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
-                                   p->ws_rows, p->row_stride, p->mm8, stream);
-      if (rc == 0) head_done = true;
-      else if (rc != FSG_E_TOOBIG && rc != FSG_E_ALIGN) return rc;
-    }
+  const int need_h = 3 * dh.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
+  const bool fused_head = p->deform_active && p->mm8_preset && p->ws_rows && !(g_tuning_flags & FSG_TUNE_SPLIT_HEAD) &&
+                          need_h > 0 && need_h <= p->row_stride;
+  // where the upload and the head go: the side stream when the caller asked for the overlap and the head is one launch
+  HeadOverlap* ho = nullptr;
+  if (p->overlap && fused_head && p->resample_active && p->arena_host) ho = head_overlap_state(st, true);
+  if (!ho) {  // this call uses the workspace in launch-stream order only: a later overlapped call must not trust an old event
+    HeadOverlap* old = head_overlap_state(st, false);
+    if (old) old->has_free = false;
   }
+  void* hstream = stream;
+  if (ho) {
+    if (!(ho->has_free && ho->ws0 == p->ws0 && ho->seq + 1 == p->ws_seq)) {
+      if (hipEventRecord(ho->ev_free, st) != hipSuccess) return FSG_E_BADARG;  // behind everything enqueued so far
+    }
+    if (hipStreamWaitEvent(ho->side, ho->ev_free, 0) != hipSuccess) return FSG_E_BADARG;
+    ho->has_free = false;
+    hstream = (void*)ho->side;
+  }
+  if (p->arena_host) {
+    if (!p->arena_dev || (p->arena_bytes & 15)) return FSG_E_BADARG;
+    FSG_TRY(fsg_copy_bytes(p->arena_dev, p->arena_host, (size_t)p->arena_bytes, hstream));
+  }
+  int head_rc = 0;
+  if (fused_head) {
+    // K1 + per-row coarse values + six-face minimum in one launch (keys arrive initialised with the parameters)
+    dh.rows = nullptr;
+    dh.row_stride = 0;
+    head_rc = fsg_sample_head_f32(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
+                                  p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
+                                  p->ws_rows, p->row_stride, p->mm8, hstream);
+    if (head_rc == 0) head_done = true;
+  }
+  if (ho) {  // whatever happened on the side stream is ordered before the rest of the sample (and before any fallback)
+    if (hipEventRecord(ho->ev_head, ho->side) != hipSuccess || hipStreamWaitEvent(st, ho->ev_head, 0) != hipSuccess)
+      return FSG_E_BADARG;
+  }
+  if (head_rc != 0 && head_rc != FSG_E_TOOBIG && head_rc != FSG_E_ALIGN) return head_rc;
   // K1: GMM draw -> ws0; the same launch resets every min/max key of the sample (unless they arrived initialised):
   // [min x,y,z | zoom min] [zoom max | 3 unused]
   if (!head_done)
@@ -119,8 +181,19 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     // K7+K8: resample + noise -> low;  K9 (+K10): min/max of the zoom-back, then zoom-back + normalise -> out
     if (!p->ws_low) return FSG_E_BADARG;
     const int m0 = p->low_shape[0], m1 = p->low_shape[1], m2 = p->low_shape[2];
+    auto mark_free = [&]() -> int {  // from here on this call touches neither ws0 nor ws_rows
+      if (!ho) return 0;
+      if (hipEventRecord(ho->ev_free, st) != hipSuccess) return FSG_E_BADARG;
+      ho->has_free = true;
+      ho->seq = p->ws_seq;
+      ho->ws0 = p->ws0;
+      return 0;
+    };
+    const bool k7_reads_ws0 = cur == p->ws0;
+    if (!k7_reads_ws0) FSG_TRY(mark_free());
     FSG_TRY(fsg_resample_noise_f32(cur, n0, n1, n2, p->rs_tab[0], p->rs_tab[1], p->rs_tab[2], p->ws_low, m0, m1, m2,
                                    p->noise_mode, p->noise, p->noise_seed, p->noise_stream, p->noise_std, stream));
+    if (k7_reads_ws0) FSG_TRY(mark_free());
     if (p->mm_slots && p->mm_nslots >= 2 && p->mm_nslots <= 64) {  // keys sharded over slots: no contended address
       FSG_TRY(fsg_zoom3d_minmax_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1,
                                             n2, p->mm_slots, p->mm_nslots, stream));
@@ -219,6 +292,11 @@ extern "C" int fsg_sample_plan_pack(fsg_sample_plan* p, const int64_t* iv, int n
   q.ev_blur_end = (void*)(uintptr_t)iv[FSG_PLAN_I_EV_END];
   q.mm_slots = (int32_t*)(uintptr_t)iv[FSG_PLAN_I_MM_SLOTS];
   q.mm_nslots = (int32_t)iv[FSG_PLAN_I_MM_NSLOTS];
+  q.arena_host = (const void*)(uintptr_t)iv[FSG_PLAN_I_ARENA_HOST];
+  q.arena_dev = (void*)(uintptr_t)iv[FSG_PLAN_I_ARENA_DEV];
+  q.arena_bytes = (uint64_t)iv[FSG_PLAN_I_ARENA_BYTES];
+  q.overlap = (int32_t)iv[FSG_PLAN_I_OVERLAP];
+  q.ws_seq = (uint64_t)iv[FSG_PLAN_I_WS_SEQ];
   *p = q;
   return 0;
 }

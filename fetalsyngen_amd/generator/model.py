@@ -42,8 +42,16 @@ _MM_SLOTS_INIT.setflags(write=False)
 
 
 import os as _os
+import weakref
 
 _NO_MM_SLOTS = _os.environ.get("FSG_NO_MM_SLOTS", "0") == "1"  # K9's keys as ONE pair (A/B runs)
+# "0" (default): parameter upload on the launch stream before the native call.  "1": upload inside the call.  "2": upload and
+# head of the sample on the library's side stream beside the previous sample's resampling tail (fsg_sample_plan::overlap).
+# Measured on MI355X (profiles/r02_g_head_overlap.txt): bit-identical results, but the two cross-queue dependencies per sample
+# cost more than the overlap returns (replay with the host out of the way: 255 us per sample in order, 263-283 us overlapped),
+# so the in-order form stays the default.
+_HEAD_OVERLAP = _os.environ.get("FSG_HEAD_OVERLAP", "0")
+_ARENA_BLOCK = 1 << 16  # device block of one sample's parameters (tables._StagingRing.SLOT)
 _SLOW_PLAN = _os.environ.get("FSG_SLOW_PLAN", "0") == "1"  # field-by-field ctypes plan instead of the flat arrays (cross-check)
 
 
@@ -157,6 +165,7 @@ class FetalSynthGen:
         if need_rows > ws["stride"]:
             ws["stride"] = (max(need_rows, 64) + 3) // 4 * 4
             ws["rows"] = torch.empty(shape[0] * shape[1] * ws["stride"], dtype=torch.float32, device=dev)
+        ws["seq"] = ws.get("seq", 0) + 1  # every use of the scratch set, whatever path makes it (fsg_sample_plan::ws_seq)
         return ws
 
     def _fill_native_plan(self, p, c, scale01, ws, out, seg_out):
@@ -279,7 +288,8 @@ class FetalSynthGen:
               FLIP=14, FIELD_DIMS=15, FIELD=18, FIELD_TABS=19, SEG_IN=22, SEG_OUT=23, SEG_IN_U8=24, BIAS_DIMS=25, BIAS=28,
               BIAS_TABS=29, RESAMPLE_ACTIVE=32, LOW_SHAPE=33, RS_TABS=36, BACK_TABS=39, BLUR_NTAPS=42, NOISE_MODE=45, NOISE=46,
               NOISE_SEED=47, NOISE_STREAM=48, SCALE01=49, WS0=50, WS1=51, WS_LOW=52, WS_ROWS=53, ROW_STRIDE=54, MM8=55,
-              MM8_PRESET=56, OUT=57, EV_BEGIN=58, EV_END=59, MM_SLOTS=60, MM_NSLOTS=61, COUNT=62)
+              MM8_PRESET=56, OUT=57, EV_BEGIN=58, EV_END=59, MM_SLOTS=60, MM_NSLOTS=61, ARENA_HOST=62, ARENA_DEV=63,
+              ARENA_BYTES=64, OVERLAP=65, WS_SEQ=66, COUNT=67)
     _TAPS_STRIDE = 132
 
     def _flat_buffers(self):
@@ -367,9 +377,37 @@ class FetalSynthGen:
         iv[I["OUT"]] = out.data_ptr()
         if events is not None:
             iv[I["EV_BEGIN"]], iv[I["EV_END"]] = events
+        if arena.pending is not None:  # staged, not yet copied: the call uploads (Arena.stage)
+            iv[I["ARENA_HOST"]], iv[I["ARENA_DEV"]], iv[I["ARENA_BYTES"]] = arena.pending[2], base, arena.pending[3]
+            iv[I["OVERLAP"]], iv[I["WS_SEQ"]] = int(self._overlap_ok(c)), ws["seq"]
         fb["iv"][:] = iv
         fb["fv"][:] = fv
         return True
+
+    def _overlap_ok(self, c) -> bool:
+        """May the head of this sample run on the library's side stream, ordered only behind the previous sample's blur
+        (fsg_sample_plan::overlap)?  Only if everything the head reads besides the arena was handed to the device before this
+        sample's host phase: seed volumes this generator has already used (same tensor object, same in-place version),
+        tap tables built in an earlier epoch, device Philox noise (a host noise field is uploaded per sample)."""
+        if _HEAD_OVERLAP != "2" or not c.arena_early or c.gmm_plan is None or c.gmm_plan.field.host is not None:
+            return False
+        if not (c.dplan.active and c.rplan.active and c.sb.pending is not None):
+            return False
+        epoch = K._EPOCH[0]
+        if c.sb.tabs.born >= epoch or (c.bplan.active and c.bias_tabs.born >= epoch):
+            return False
+        seen, ok = self.__dict__.setdefault("_seen_parts", {}), True
+        for part in c.label_parts:
+            key = part.data_ptr()
+            hit = seen.get(key)
+            if hit is None or hit[0]() is not part or hit[1] != part._version:
+                if len(seen) > 1024:
+                    seen.clear()
+                seen[key] = (weakref.ref(part), part._version, epoch)  # first use (or rewritten in place): from the next sample on
+                ok = False
+            elif hit[2] >= epoch:
+                ok = False
+        return ok
 
     def _fast_operands(self, c) -> bool:
         """The operand checks of _native_operands, once per distinct (segmentation, seed volumes) set; False when the
@@ -419,7 +457,11 @@ class FetalSynthGen:
         fb = self._flat
         rc = lib.fsg_sample_pack_run(fb["ivp"], self._I["COUNT"], fb["fvp"], 17, fb["tbp"], K._stream(dev))
         if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
+            if c.arena.pending is not None:
+                c.arena.flush(False)  # outside the fused domain: the parameters (keys re-initialised) for the fallback path
             return None
+        if c.arena.pending is not None:
+            c.arena.flush(rc == 0)
         _lib.check(rc, "fsg_sample_pack_run")
         f32_view = c.arena.f32
         c.mus, c.sigmas = f32_view(c.gm_off[0], (c.gm_off[2],)), f32_view(c.gm_off[1], (c.gm_off[2],))
@@ -734,11 +776,34 @@ class FetalSynthGen:
 
     def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
         with _rng.use(self.rng):
+            K._EPOCH[0] += 1
             arena = T.Arena()
+            # The device block of THIS sample's parameters was allocated during the previous sample's host phase, i.e. before
+            # that sample's kernels were enqueued: whatever owned the block before was last used ahead of them, so the upload
+            # may be ordered behind the previous sample's blur alone (fsg_sample_plan::overlap).  The next sample's block
+            # is allocated here, before this sample enqueues anything.
+            dev = torch.device(self.device)
+            nxt = self.__dict__.setdefault("_arena_next", {})
+            akey = (dev.index, K._stream(dev).value)
+            block = nxt.pop(akey, None) if _HEAD_OVERLAP != "0" else None
+            early = block is not None
+            if _HEAD_OVERLAP != "0":
+                if block is None:
+                    block = torch.empty(_ARENA_BLOCK, dtype=torch.uint8, device=dev)
+                if len(nxt) > 8:
+                    nxt.clear()
+                nxt[akey] = torch.empty(_ARENA_BLOCK, dtype=torch.uint8, device=dev)
             c = self._prepare(image, segmentation, seeds, genparams, arena, segmentation_u8)
-            arena.upload(self.device)
-            if self._native_ok(c) and not _SLOW_PLAN:
-                native = self._run_native_fast(c, scale01)
+            c.arena_early = early
+            fast = self._native_ok(c) and not _SLOW_PLAN
+            if not (fast and block is not None and arena.stage(self.device, block)):
+                arena.upload(self.device)
+            if fast:
+                try:
+                    native = self._run_native_fast(c, scale01)
+                finally:
+                    if arena.pending is not None:  # the native call was not reached: upload on the launch stream now
+                        arena.flush(False)
                 if native is not None:
                     return native[0], native[1], None, self._synth_params(c, {})
             self._resolve(c)

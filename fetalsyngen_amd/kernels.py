@@ -92,6 +92,12 @@ def _device_table(tab, device):
     return d
 
 
+# Bumped by FetalSynthGen once per sample.  A DeviceTables object remembers the epoch it was built in: its upload was enqueued
+# on the launch stream during THAT sample's host phase, so work that is ordered only behind the previous sample (the head of a
+# sample on the library's side stream, fsg_sample_plan::overlap) may read it from the next sample on, not before.
+_EPOCH = [0]
+
+
 class DeviceTables:
     """Three per-axis tap tables resident on the device.
 
@@ -100,6 +106,7 @@ class DeviceTables:
 
     def __init__(self, tabs, device, arena: Arena | None = None):
         self.lengths = tuple(len(t) for t in tabs)
+        self.born = _EPOCH[0]
         self._dev = [_device_table(t, device) for t in tabs]
         self.ptrs = tuple(C.c_void_p(d.data_ptr()) for d in self._dev)  # the device copies never move
         self.ptrs_i = tuple(int(d.data_ptr()) for d in self._dev)        # the same as plain integers (flat plan arrays)

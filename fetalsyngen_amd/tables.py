@@ -230,6 +230,41 @@ class Arena:
         self.__dict__.pop("_f32", None)
         return self.dev
 
+    def stage(self, device, dev_tensor) -> bool:
+        """Deferred form of `upload`: the items go into a pinned slot and `dev_tensor` (uint8, device, at least the arena's
+        size) becomes the arena's device block, but NO copy is enqueued -- the native call that consumes the arena does it
+        (fsg_sample_plan::arena_host / arena_dev / arena_bytes), possibly on its side stream.  `flush` must follow.
+        False (nothing staged) when the arena does not fit a slot or pinned memory is unavailable."""
+        size = max(self._size, self.ALIGN)
+        n = (size + 15) // 16 * 16
+        if dev_tensor is None or dev_tensor.numel() < n or n > _StagingRing.SLOT or not _can_pin():
+            return False
+        ring = _staging_ring(device)
+        if ring is None:
+            return False
+        slot, host = ring.acquire()
+        hv = host.numpy()
+        for off, arr in self._items:
+            hv[off : off + arr.nbytes] = arr.view(np.uint8).reshape(-1)
+        self.dev = dev_tensor
+        self.base = dev_tensor.data_ptr()
+        self.__dict__.pop("_f32", None)
+        self.pending = (ring, slot, host.data_ptr(), n)
+        return True
+
+    pending = None
+
+    def flush(self, copied: bool):
+        """After `stage`: `copied` = a native call has enqueued the copy (and ordered the current stream behind it);
+        otherwise it is enqueued here, on the current stream.  Then the pinned slot is handed back to the ring."""
+        ring, slot, host_ptr, n = self.pending
+        self.pending = None
+        if not copied:
+            from . import _lib
+
+            _lib.check(_lib.load().fsg_copy_bytes(self.dev.data_ptr(), host_ptr, n, ring.raw_stream()), "fsg_copy_bytes")
+        ring.release(slot)
+
     def ptr(self, off: int) -> int:
         return self.base + off
 

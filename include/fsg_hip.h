@@ -429,6 +429,21 @@ typedef struct fsg_sample_plan {
   int32_t mm_nslots;
   const uint8_t* seg_in_u8;      /* optional uint8 copy of seg_in (same values): the label gather then reads 1 B/voxel
                                     (fsg_warp_f32_u8_to_f32); seg_in stays required as the fallback source */
+  /* parameter upload as part of the call (optional): arena_bytes (multiple of 16) from the device-visible pinned block
+   * arena_host to arena_dev -- the block every pointer above with small per-sample content points into -- before the first
+   * kernel.  The caller must not reuse arena_host before work enqueued on `stream` AFTER this call has completed. */
+  const void* arena_host;
+  void* arena_dev;
+  uint64_t arena_bytes;
+  /* overlap != 0: the upload and the head of the sample (K1 + per-row coarse values + face minima) run on a side stream
+   * owned by the library, ordered behind the point of the PREVIOUS call on `stream` after which ws0 / ws_rows are no longer
+   * touched (its blur), so that they execute beside the previous sample's resampling tail; `stream` waits for them before
+   * the warp.  ws_seq identifies consecutive uses of the workspace: the previous call's ordering point is honoured only if
+   * it carried ws_seq - 1 and the same ws0, otherwise the side stream is ordered behind everything enqueued on `stream`
+   * so far.  Requires arena_dev to be private to this call and not reused by the next one (a ring of >= 2 blocks).
+   * Results are those of overlap == 0. */
+  int32_t overlap;
+  uint64_t ws_seq;
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
 /* B samples with one call: plan b runs on streams[b % nstreams] (hipStream_t handles).  The caller orders those streams
@@ -447,7 +462,8 @@ enum {
   FSG_PLAN_I_BLUR_NTAPS = 42, FSG_PLAN_I_NOISE_MODE = 45, FSG_PLAN_I_NOISE = 46, FSG_PLAN_I_NOISE_SEED = 47,
   FSG_PLAN_I_NOISE_STREAM = 48, FSG_PLAN_I_SCALE01 = 49, FSG_PLAN_I_WS0 = 50, FSG_PLAN_I_WS1 = 51, FSG_PLAN_I_WS_LOW = 52,
   FSG_PLAN_I_WS_ROWS = 53, FSG_PLAN_I_ROW_STRIDE = 54, FSG_PLAN_I_MM8 = 55, FSG_PLAN_I_MM8_PRESET = 56, FSG_PLAN_I_OUT = 57,
-  FSG_PLAN_I_EV_BEGIN = 58, FSG_PLAN_I_EV_END = 59, FSG_PLAN_I_MM_SLOTS = 60, FSG_PLAN_I_MM_NSLOTS = 61, FSG_PLAN_I_COUNT = 62
+  FSG_PLAN_I_EV_BEGIN = 58, FSG_PLAN_I_EV_END = 59, FSG_PLAN_I_MM_SLOTS = 60, FSG_PLAN_I_MM_NSLOTS = 61, FSG_PLAN_I_ARENA_HOST = 62,
+  FSG_PLAN_I_ARENA_DEV = 63, FSG_PLAN_I_ARENA_BYTES = 64, FSG_PLAN_I_OVERLAP = 65, FSG_PLAN_I_WS_SEQ = 66, FSG_PLAN_I_COUNT = 67
 };
 enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_GAMMA = 15, FSG_PLAN_F_NOISE_STD = 16, FSG_PLAN_F_COUNT = 17 };
 #define FSG_PLAN_TAPS_STRIDE 132

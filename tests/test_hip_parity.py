@@ -1127,6 +1127,71 @@ def test_config4_384_hot_path_properties(K):
             assert abs(float(mean[l]) - float(mus[l])) < 0.05 and abs(float(var[l]) ** 0.5 - float(sig[l])) < 0.05
 
 
+@pytest.mark.parametrize("shape", [(64, 56, 72), (256, 256, 256)])
+def test_head_overlap_reproduces_the_in_order_stream(K, shape):
+    """fsg_sample_plan::overlap: the parameter upload and the head of sample n+1 run on the library's side stream beside the
+    resampling tail of sample n.  The results must be those of the plain in-order launch (FSG_HEAD_OVERLAP=0: upload on the
+    launch stream before the call) bit for bit, for a sequence that keeps invalidating the ordering point: seed banks the
+    generator has not used yet, a bank rewritten in place, a `sample_batch` in between, a second launch stream, and user
+    work on the outputs enqueued between the calls (256^3: kernels long enough for a missing dependency to be hit)."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.generator import model as M
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    nsub = 3
+    subjects = []
+    for v in range(nsub):
+        seg, seeds = make_seed_volumes(shape, v)
+        subjects.append((dev(seg), SeedBank(seeds, DEV)))
+    small = shape[0] < 128
+    gen = make_generator(shape, DEV, rng="device", prob=1.0, nonlin_scale=(0.08, 0.2) if small else (0.03, 0.06),
+                         bf_scale=(0.03, 0.12) if small else (0.004, 0.02))
+    other = torch.cuda.Stream()
+
+    def run(mode):
+        prev = M._HEAD_OVERLAP
+        M._HEAD_OVERLAP = mode
+        try:
+            sums = []
+            keep = None
+            for i in range(14):
+                np.random.seed(100 + i)
+                torch.manual_seed(100 + i)
+                seg, bank = subjects[i % nsub]
+                if i == 6:  # a bank the generator has never seen, uploaded right before the call
+                    seg2, seeds2 = make_seed_volumes(shape, 7)
+                    seg, bank = dev(seg2), SeedBank(seeds2, DEV)
+                if i == 8:  # rewritten in place (same storage, new _version)
+                    for d in bank.vol.values():
+                        for t in d.values():
+                            t.copy_(t.flip(0).contiguous())
+                if i == 9:
+                    out, lab, _, _ = gen.sample_batch([(None, seg, bank)], streams=1)
+                    out, lab = out[0], lab[0]
+                elif i == 11:
+                    with torch.cuda.stream(other):
+                        other.wait_stream(torch.cuda.current_stream())
+                        out, lab, _, _ = gen.sample(None, seg, bank)
+                    torch.cuda.current_stream().wait_stream(other)
+                else:
+                    out, lab, _, _ = gen.sample(None, seg, bank)
+                keep = (out * 2.0).sum()  # user work on the launch stream between the calls; its block is freed next turn
+                sums.append((out.double().sum().item(), lab.double().sum().item(), out[3, 5, 7].item(), keep.item()))
+                if i == 8:
+                    for d in bank.vol.values():
+                        for t in d.values():
+                            t.copy_(t.flip(0).contiguous())
+            torch.cuda.synchronize()
+            return sums
+        finally:
+            M._HEAD_OVERLAP = prev
+
+    want = run("0")
+    got = run("2")
+    assert got == want
+    assert run("1") == want  # upload inside the call, launch stream only
+
+
 @pytest.mark.parametrize("prob", [1.0, 0.6])
 def test_sample_batch_equals_consecutive_samples(K, tmp_path, prob):
     """B volumes per call.  `sample_batch` (one parameter upload, one fsg_sample_run_batch call, 1 or 2 HIP
