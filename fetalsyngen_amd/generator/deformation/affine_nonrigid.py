@@ -24,10 +24,11 @@ from ...utils.generation import fast_3D_interp_torch, make_affine_matrix
 class DeformPlan:
     """All random draws of one deformation, host side."""
 
-    __slots__ = ("active", "flip", "A", "c2", "field_small", "params")
+    __slots__ = ("active", "flip", "A", "c2", "field_small", "params", "A_np", "c2_np")
 
     def __init__(self):
         self.active, self.flip, self.A, self.c2, self.field_small = False, False, None, None, None
+        self.A_np, self.c2_np = None, None  # numpy twins of A (float32) / c2 (float64) when the planner has them at hand
         self.params = {"affine": None, "non_rigid": None, "flip": False}
 
 

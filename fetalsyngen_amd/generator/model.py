@@ -100,6 +100,8 @@ class FetalSynthGen:
         self.rng = rng  # None: module default (fetalsyngen_amd.rng.get_mode())
         self.native_pipeline = True  # one fsg_sample_run call per sample when the inputs allow it
         self.blur_events = None      # set to a list to have HIP events recorded around each sample's blur passes
+        self.blur_events_every = 1   # ... of every k-th sample only (an event record is a barrier packet: ~5.5 us of bubble)
+        self._blur_tick = 0
         self._ws = {}
 
     def prewarm(self, shape=None) -> int:
@@ -326,9 +328,10 @@ class FetalSynthGen:
         if dplan.active:
             iv[I["DEFORM_ACTIVE"]] = 1
             iv[I["FLIP"]] = int(bool(dplan.flip))
-            fv[0:9] = dplan.A.reshape(-1).tolist()
+            a_np, c2_np = dplan.A_np, dplan.c2_np  # left by _draw_all_fast (no torch round trip)
+            fv[0:9] = a_np.ravel().tolist() if a_np is not None else dplan.A.reshape(-1).tolist()
             fv[9:12] = fb["centre"]
-            fv[12:15] = dplan.c2.to(torch.float32).tolist()
+            fv[12:15] = c2_np.astype(np.float32).tolist() if c2_np is not None else dplan.c2.to(torch.float32).tolist()
             if c.sb.pending is not None:
                 off, fshape = c.sb.pending
                 iv[I["FIELD_DIMS"]:I["FIELD_DIMS"] + 3] = fshape[:3]
@@ -447,7 +450,9 @@ class FetalSynthGen:
         events = None
         lib = _lib.load()
         if self.blur_events is not None and c.rplan.active:
-            events = (lib.fsg_event_create(), lib.fsg_event_create())
+            self._blur_tick += 1
+            if self._blur_tick % self.blur_events_every == 0:
+                events = (lib.fsg_event_create(), lib.fsg_event_create())
         if not self._flat_plan(c, scale01, out, seg_out, ws, events):
             return None
         if events is not None:
@@ -639,11 +644,13 @@ class FetalSynthGen:
             rot = np.array([(mr2 * ul[1] - mr) / 180.0 * pi, (mr2 * ul[2] - mr) / 180.0 * pi, (mr2 * ul[3] - mr) / 180.0 * pi])
             shr = np.array([ms2 * ul[4] - ms, ms2 * ul[5] - ms, ms2 * ul[6] - ms])
             scl = np.array([1 + (mc2 * ul[7] - mc), 1 + (mc2 * ul[8] - mc), 1 + (mc2 * ul[9] - mc)])
-            dplan.A = torch.from_numpy(make_affine_matrix(rot, shr, scl).astype(np.float32))
+            dplan.A_np = make_affine_matrix(rot, shr, scl).astype(np.float32)
+            dplan.A = torch.from_numpy(dplan.A_np)
             ut = torch.rand(3, dtype=torch.float64).tolist()  # float64 draw, always consumed
             c32, r64 = sd._shape_lists(tuple(shape)[0:3])
             centre = np.array([c32[0] + (2 * (r64[0] * ut[0]) - r64[0]), c32[1] + (2 * (r64[1] * ut[1]) - r64[1]),
                                c32[2] + (2 * (r64[2] * ut[2]) - r64[2])])
+            dplan.c2_np = centre
             dplan.c2 = torch.from_numpy(centre)
             nr_params = {}
             if nl:
