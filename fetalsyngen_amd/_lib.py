@@ -171,7 +171,7 @@ SIGNATURES = {
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
 }
 SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32]),
-                   "fsg_event_create": (C.c_void_p, [])}
+                   "fsg_event_create": (C.c_void_p, []), "fsg_sample_plan_layout": (C.c_int64, [I])}
 
 _lib = None
 

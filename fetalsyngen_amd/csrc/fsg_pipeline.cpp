@@ -6,6 +6,7 @@
 // interpreter between launches costs as much as the kernels; semantics and results are those of calling the
 // entry points one by one (tests/test_hip_parity.py::test_native_pipeline_equals_stagewise).
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -223,6 +224,17 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     if (e != hipSuccess) return (int)e;
   }
   return 0;
+}
+
+extern "C" int64_t fsg_sample_plan_layout(int which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(fsg_sample_plan);
+    case 1: return (int64_t)offsetof(fsg_sample_plan, blur_taps);
+    case 2: return (int64_t)offsetof(fsg_sample_plan, out);
+    case 3: return (int64_t)offsetof(fsg_sample_plan, seg_in_u8);
+    case 4: return (int64_t)offsetof(fsg_sample_plan, ws_seq);
+    default: return -1;
+  }
 }
 
 // The plan from two flat arrays instead of ~60 field writes through an FFI (the Python mirror spends 41 us filling the

@@ -446,6 +446,9 @@ typedef struct fsg_sample_plan {
   uint64_t ws_seq;
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
+/* Layout check for FFI mirrors of the struct: which = 0 -> sizeof(fsg_sample_plan); 1 / 2 / 3 / 4 -> offsetof blur_taps / out /
+ * seg_in_u8 / ws_seq; anything else -> -1.  Callable without a GPU. */
+int64_t fsg_sample_plan_layout(int which);
 /* B samples with one call: plan b runs on streams[b % nstreams] (hipStream_t handles).  The caller orders those streams
  * behind the upload of every plan's parameters and waits for them afterwards; per sample the work is exactly
  * fsg_sample_run's (reference: B consecutive FetalSynthGen.sample calls, generator/model.py:231-276; the reference's

@@ -76,3 +76,21 @@ def test_product_refuses_cpu_tensors():
         K.gamma(torch.zeros(2, 2, 2), 1.0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         K.blur_axis(torch.zeros(4, 4, 4), 0, [0.25, 0.5, 0.25])
+
+
+def test_sample_plan_mirror_has_the_c_layout():
+    """The ctypes mirror of fsg_sample_plan against the compiled struct: total size and the offsets of a field behind the
+    large tap array, of the last r01 field, and of the two newest ones (a mirror that drifts would hand every later
+    pointer to the wrong slot)."""
+    import ctypes as C
+
+    from fetalsyngen_amd import _lib
+
+    lib = _lib.load()
+    P = _lib.SamplePlan
+    assert lib.fsg_sample_plan_layout(0) == C.sizeof(P)
+    assert lib.fsg_sample_plan_layout(1) == P.blur_taps.offset
+    assert lib.fsg_sample_plan_layout(2) == P.out.offset
+    assert lib.fsg_sample_plan_layout(3) == P.seg_in_u8.offset
+    assert lib.fsg_sample_plan_layout(4) == P.ws_seq.offset
+    assert lib.fsg_sample_plan_layout(99) == -1
