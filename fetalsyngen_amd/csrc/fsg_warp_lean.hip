@@ -52,7 +52,7 @@ __device__ __forceinline__ void lean_store_label(__amdgpu_buffer_rsrc_t r, unsig
   __builtin_amdgcn_raw_buffer_store_b8(v, r, elem, 0, 0);
 }
 
-// ABL (diagnostic builds only, tools/warp_ab.sh): 1 = every vector-memory access predicated off at run time (arithmetic and
+// ABL (diagnostic instantiations only, tools/kernel_bench.py --variant 8 / 9): 1 = every vector-memory access predicated off at run time (arithmetic and
 // LDS traffic only), 2 = trivial sampling positions (memory traffic and blends only).  0 in every product launch.
 template <typename ST, typename DT, bool HAS_LIN, bool HAS_NN, bool FAST, int KZ, int WI, int ABL = 0>
 __global__ __launch_bounds__(1024, 8) void warp_lean_kernel(FsgDeformK D, const int32_t* __restrict__ mm6,
@@ -244,7 +244,7 @@ int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const fl
 #define FSG_LEAN(L, N, F) \
   hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E, \
                      pace)
-  if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {  // diagnostic builds (tools/warp_ab.sh)
+  if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {  // diagnostic instantiations (tools/kernel_bench.py --variant 8 / 9)
     if (g_lean_ablate == 1)
       hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 1>), grid, block, 0, st, D, mm6, src_lin, out_lin,
                          src_nn, out_nn, E, pace);
