@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void blur_contig_long(const float* __restrict_
 // accumulates its taps in ascending order with fmaf exactly as the single-axis kernels do, on the same values, so the
 // result is bit-identical to running them one after the other.
 constexpr int YZ_MAXR = 8;
-constexpr int YZ_TL = 8;               // y outputs per thread (register sliding window)
+constexpr int YZ_TL = 4;               // y outputs per thread (register sliding window); 4 beats 8 and 16 at 256^3 (25.3 / 26.7 / 32.7 us at R = 4: more workgroups per CU, the larger y halo is served by L2)
 constexpr int YZ_ROWS = 4 * YZ_TL;     // y rows per workgroup
 
 // Workgroup = YZ_ROWS consecutive y rows of one x-plane over the FULL z extent (nz <= 512), thread = (float4 z-column,
