@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
     den = 1.0f - mnq;
   }
   const UniDiv ud = unidiv_make(mx);
+  const UniDiv udd = unidiv_make(den);  // the scaling's second divisor (1 - min/max) is uniform as well
   __syncthreads();
   auto row_tap = [&](int jj) {
     fsg_tap b = tb[jj];
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
 #else
         float t = unidiv(ud, v[u]);
 #endif
-        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : (t - mnq) / den);
+        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : unidiv(udd, t - mnq));
         v[u] = t;
       }
     }

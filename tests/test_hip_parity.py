@@ -337,6 +337,20 @@ def test_uniform_division_in_k9b_is_the_ieee_quotient(K):
     mm = torch.tensor([int(np.float32(0.0).view(np.int32)), int(d32.view(np.int32))], dtype=torch.int32, device=DEV)
     assert np.array_equal(host(K.zoom_normalise(x, zt, mm, 0)), tiny / d32)
     assert np.array_equal(host(K.zoom_normalise(x, zt, mm, 1)), tiny / d32)  # min = 0: (t - 0) / 1
+    # mode 1 with a non-zero minimum: the second division, by the uniform (1 - min/max), goes through the same shortcut.
+    # Every significand of [1, 2) again, for minima that make the divisor ordinary, close to 1 and all-ones
+    vals = (mant | np.uint32(127 << 23)).view(np.float32).reshape(shape)
+    x = dev(vals)
+    for mx, mn in [(1.9999999, 1.0), (2.0, 1.0), (255.0, 3.0), (1.9999999, 1e-7), (300.0, 299.0),
+                   (float(np.float32(np.uint32(0x40000000).view(np.float32))), float(np.float32(np.uint32(0x33800000).view(np.float32))))]:
+        mx32, mn32 = np.float32(mx), np.float32(mn)
+        mm = torch.tensor([int(mn32.view(np.int32)), int(mx32.view(np.int32))], dtype=torch.int32, device=DEV)
+        mnq = mn32 / mx32
+        den = np.float32(1.0) - mnq
+        t = vals / mx32
+        want = (t - mnq) if den == np.float32(1.0) else ((t - mnq) / den)
+        got = host(K.zoom_normalise(x, zt, mm, 1))
+        assert np.array_equal(got, want.astype(np.float32)), (mx, mn, int((got != want).sum()))
 
 
 def test_blur_yz_fused_equals_two_passes(K):
