@@ -463,6 +463,11 @@ def run(args, rank, world, local):
     for i in range(setup_samples):
         step(10_000_000 + i)
     torch.cuda.synchronize()
+    # everything alive now (modules, tables, caches) is long-lived: keep the cyclic collector from re-scanning it inside the
+    # timed steps (a full collection is ~1 ms, a sixth of the driver's 20-step region)
+    import gc
+    gc.collect()
+    gc.freeze()
     gen.blur_events = []
     gen.blur_events_every = 4  # every 4th sample: each event record is a barrier packet in the launch queue (~5.5 us of bubble)
     for i in range(args.warmup):
