@@ -197,6 +197,17 @@ def test_warp_identity_and_flip_properties(K):
     o = host(out)
     assert np.array_equal(o[1:, 1:, 1:], img[1:, 1:, 1:])
     assert not o[0].any() and not o[:, 0].any() and not o[:, :, 0].any()
+    # half a voxel along z: interior outputs are the mean of two z-neighbours; the last column's position (n2 - 0.5) is clamped
+    # onto the last column exactly -- the lean kernel then reads the pair one to the LEFT with weights (0, 1) -- and must
+    # return the last column itself, like the reference's clamped upper neighbour with weights (1, 0)
+    c_half = c.astype(np.float32).copy()
+    c_half[2] += 0.5
+    spech = K.DeformSpec(shape, eye, c, c_half, False, device=DEV)
+    outh, _ = K.warp(spech, K.coords_minmax(spech), src_lin=dev(img))
+    oh = host(outh)
+    want = img[1:, 1:, :-1] * np.float32(0.5) + img[1:, 1:, 1:] * np.float32(0.5)
+    assert np.array_equal(oh[1:, 1:, :-1], want)
+    assert np.array_equal(oh[1:, 1:, -1], img[1:, 1:, -1])
     specf = K.DeformSpec(shape, eye, c, c.astype(np.float32), True, device=DEV)
     _, f1 = K.warp(specf, mm6, src_nn=dev(img))
     _, f2 = K.warp(specf, mm6, src_nn=f1)
