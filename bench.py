@@ -615,7 +615,7 @@ def run(args, rank, world, local):
             outputs = {"cpu_contract": "float32 image (1,H,W,D) + int64 labels on the CPU (pinned ring), reference data/datasets.py:315-323",
                        "cpu_contract_batched": "the same contract, 4 samples per native call on 2 HIP streams, collated (4,1,H,W,D), one D2H copy per tensor and batch",
                        "cpu_f16_u8_batched": "opt-in: float16 image + uint8 labels on the CPU (48 MiB instead of 192 MiB per volume), batches of 4",
-                       "device_resident": "float32 image + uint8 labels in HBM",
+                       "device_resident": "float32 image + uint8 labels in HBM (the fused warp writes the uint8 labels itself)",
                        "device_resident_batched": "float32 image + uint8 labels in HBM, 4 samples per native call on 2 HIP streams"}[key]
             c5[key] = {"volumes_per_s": round(world * n_stream / dts, 1), "s": round(dts, 3), "outputs": outputs}
         del ds

@@ -98,6 +98,7 @@ class SamplePlan(C.Structure):
         ("arena_bytes", C.c_uint64),
         ("overlap", C.c_int32),
         ("ws_seq", C.c_uint64),
+        ("seg_out_u8", C.c_void_p),
     ]
 
 

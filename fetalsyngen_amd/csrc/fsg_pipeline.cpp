@@ -114,7 +114,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
 
   if (p->deform_active) {
     // K2/K3: coarse rows, floor(min) margins; K4(+K5): fused warp of the image and the labels -> ws1
-    if (!p->seg_in || !p->seg_out) return FSG_E_BADARG;
+    if (!p->seg_in || (!p->seg_out && !p->seg_out_u8) || (p->seg_out_u8 && !p->seg_in_u8)) return FSG_E_BADARG;
     fsg_deform d = p->deform;
     const int need = 3 * d.field_dims[2] + (has_bias ? p->epi.bias_dims[2] : 0);
     if (head_done) {
@@ -139,9 +139,13 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       FSG_TRY(rc);
     }
     int rw = FSG_E_ALIGN;
-    if (p->seg_in_u8)  // uint8 copy of the labels: 1 B/voxel gathered instead of 4 (same output)
-      rw = fsg_warp_f32_u8_to_f32(&d, p->mm8, cur, other, p->seg_in_u8, p->seg_out, &p->epi, stream);
-    if (rw == FSG_E_ALIGN) rw = fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream);
+    if (p->seg_out_u8) {  // uint8 labels in and out (same values: labels are integers 0..255)
+      rw = fsg_warp_f32_u8(&d, p->mm8, cur, other, p->seg_in_u8, p->seg_out_u8, &p->epi, stream);
+    } else {
+      if (p->seg_in_u8)  // uint8 copy of the labels: 1 B/voxel gathered instead of 4 (same output)
+        rw = fsg_warp_f32_u8_to_f32(&d, p->mm8, cur, other, p->seg_in_u8, p->seg_out, &p->epi, stream);
+      if (rw == FSG_E_ALIGN) rw = fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream);
+    }
     FSG_TRY(rw);
     float* t = cur; cur = other; other = t;
   } else {
@@ -309,6 +313,7 @@ extern "C" int fsg_sample_plan_pack(fsg_sample_plan* p, const int64_t* iv, int n
   q.arena_bytes = (uint64_t)iv[FSG_PLAN_I_ARENA_BYTES];
   q.overlap = (int32_t)iv[FSG_PLAN_I_OVERLAP];
   q.ws_seq = (uint64_t)iv[FSG_PLAN_I_WS_SEQ];
+  q.seg_out_u8 = (uint8_t*)(uintptr_t)iv[FSG_PLAN_I_SEG_OUT_U8];
   *p = q;
   return 0;
 }

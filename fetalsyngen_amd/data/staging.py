@@ -104,6 +104,9 @@ class PrefetchingStream:
         self.keep = keep
         self.batch_size, self.image_dtype, self.batch_streams = batch_size, image_dtype, batch_streams
         self._stager = None
+        # uint8 labels straight from the fused warp wherever the consumer gets uint8 anyway (the int64 contract keeps the
+        # float32 labels and the reference's `.long()` semantics for any label value)
+        self._labels_u8 = (not to_host) or label_dtype == torch.uint8
 
     def __len__(self):
         return len(self.indices)
@@ -114,7 +117,8 @@ class PrefetchingStream:
         segm = self.ds._segmentation(idx)
         name = self.ds._sub_ses_idx(idx)
         seeds = self.ds._seeds_for(name)
-        out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True)
+        # device-resident hand-over: the fused warp writes the uint8 labels itself (no float32 labels, no conversion pass)
+        out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True, labels_u8=self._labels_u8)
         return out, seg, name
 
     def _produce_batch(self, idxs):
@@ -132,7 +136,8 @@ class PrefetchingStream:
                 names.append(name)
                 yield (None, ds._segmentation(idx), ds._seeds_for(name))
 
-        out, seg, _imgs, _params = gen.sample_batch(items(), scale01=True, streams=self.batch_streams, lazy_items=len(idxs))
+        out, seg, _imgs, _params = gen.sample_batch(items(), scale01=True, streams=self.batch_streams, lazy_items=len(idxs),
+                                                    labels_u8=self._labels_u8)
         return out, seg, names
 
     def _iter_batches(self):
@@ -141,7 +146,7 @@ class PrefetchingStream:
         if not self.to_host:
             for ch in chunks:
                 out, seg, names = self._produce_batch(ch)
-                yield {"image": out.unsqueeze(1), "label": seg.to(torch.uint8).unsqueeze(1), "name": names}
+                yield {"image": out.unsqueeze(1), "label": seg.unsqueeze(1), "name": names}
             return
         pending = deque()
         stagers = {}  # a ragged last batch gets its own (smaller) ring
@@ -168,7 +173,7 @@ class PrefetchingStream:
         if not self.to_host:
             for i in self.indices:
                 out, seg, name = self._produce(i)
-                yield {"image": out.unsqueeze(0), "label": seg.to(torch.uint8).unsqueeze(0), "name": name}
+                yield {"image": out.unsqueeze(0), "label": seg.unsqueeze(0), "name": name}
             return
         pending = deque()
         for i in self.indices:

@@ -194,11 +194,17 @@ class FetalSynthGen:
         if spec is not None:
             p.deform_active = 1
             p.deform = spec.c
-            p.seg_in, p.seg_out = seg.data_ptr(), seg_out.data_ptr()
+            p.seg_in = seg.data_ptr()
             # only for a caller-owned device tensor (stable identity): a converted copy would be a new cache entry per call
             twin = self._label_twin(seg) if seg is c.segmentation else None
             if twin is not None:
                 p.seg_in_u8 = twin.data_ptr()
+            if seg_out.dtype == torch.uint8:  # uint8 labels out: written by the warp from the uint8 source
+                if twin is None:
+                    return False
+                p.seg_out_u8 = seg_out.data_ptr()
+            else:
+                p.seg_out = seg_out.data_ptr()
         p.epi = K._epilogue(c.gam, c.bias_dev, c.bias_tabs, shape)
         c.keep.append(p.epi)
         if rplan.active:
@@ -291,7 +297,7 @@ class FetalSynthGen:
               BIAS_TABS=29, RESAMPLE_ACTIVE=32, LOW_SHAPE=33, RS_TABS=36, BACK_TABS=39, BLUR_NTAPS=42, NOISE_MODE=45, NOISE=46,
               NOISE_SEED=47, NOISE_STREAM=48, SCALE01=49, WS0=50, WS1=51, WS_LOW=52, WS_ROWS=53, ROW_STRIDE=54, MM8=55,
               MM8_PRESET=56, OUT=57, EV_BEGIN=58, EV_END=59, MM_SLOTS=60, MM_NSLOTS=61, ARENA_HOST=62, ARENA_DEV=63,
-              ARENA_BYTES=64, OVERLAP=65, WS_SEQ=66, COUNT=67)
+              ARENA_BYTES=64, OVERLAP=65, WS_SEQ=66, SEG_OUT_U8=67, COUNT=68)
     _TAPS_STRIDE = 132
 
     def _flat_buffers(self):
@@ -337,10 +343,16 @@ class FetalSynthGen:
                 iv[I["FIELD_DIMS"]:I["FIELD_DIMS"] + 3] = fshape[:3]
                 iv[I["FIELD"]] = base + off
                 iv[I["FIELD_TABS"]:I["FIELD_TABS"] + 3] = c.sb.tabs.ptrs_i
-            iv[I["SEG_IN"]], iv[I["SEG_OUT"]] = c.seg.data_ptr(), seg_out.data_ptr()
             twin = self._label_twin(c.seg) if c.seg is c.segmentation else None
             if twin is not None:
                 iv[I["SEG_IN_U8"]] = twin.data_ptr()
+            iv[I["SEG_IN"]] = c.seg.data_ptr()
+            if seg_out.dtype == torch.uint8:  # uint8 labels out (device-resident hand-over): needs the uint8 source
+                if twin is None:
+                    return False
+                iv[I["SEG_OUT_U8"]] = seg_out.data_ptr()
+            else:
+                iv[I["SEG_OUT"]] = seg_out.data_ptr()
         if c.g is not None:
             fv[15] = float(np.float32(float(c.g)))
         if c.bplan.active:
@@ -435,8 +447,9 @@ class FetalSynthGen:
             raise ValueError(f"mus / sigmas tables of {c.gm_off[2]} entries (need 1..256)")
         return True
 
-    def _run_native_fast(self, c, scale01):
-        """Prepared sample -> (image, labels) through fsg_sample_pack_run, or None (caller falls back)."""
+    def _run_native_fast(self, c, scale01, labels_u8=False):
+        """Prepared sample -> (image, labels) through fsg_sample_pack_run, or None (caller falls back).  labels_u8: the labels
+        as a uint8 volume (written by the warp itself; without a deformation the cached uint8 copy of the input)."""
         from .. import _lib
 
         if not self._fast_operands(c):
@@ -446,7 +459,15 @@ class FetalSynthGen:
         b2 = int(c.bplan.grid.shape[2]) if c.bplan.active else 0
         ws = self._workspace(c.shape, 3 * f2 + b2 if c.dplan.active else 0)
         out = torch.empty(c.shape, dtype=torch.float32, device=dev)
-        seg_out = torch.empty_like(c.seg) if c.dplan.active else c.seg
+        if labels_u8:
+            if c.dplan.active:
+                seg_out = torch.empty(c.shape, dtype=torch.uint8, device=dev)
+            else:
+                seg_out = self._label_twin(c.seg) if c.seg is c.segmentation else None
+                if seg_out is None:
+                    return None
+        else:
+            seg_out = torch.empty_like(c.seg) if c.dplan.active else c.seg
         events = None
         lib = _lib.load()
         if self.blur_events is not None and c.rplan.active:
@@ -781,7 +802,15 @@ class FetalSynthGen:
     def _synth_params(self, c, artifacts):
         return self._params(c.selected_seeds, c.seed_intensities, c.dplan, c.g, c.bplan, c.rplan, c.nplan, artifacts)
 
-    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None):
+    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None, labels_u8: bool = False):
+        """labels_u8: return the labels as uint8 (same values; written as such by the fused warp where the fused path runs,
+        converted afterwards otherwise)."""
+        if labels_u8:
+            out, seg, img, params = self._pipeline_f(image, segmentation, seeds, genparams, scale01, segmentation_u8, True)
+            return out, (seg if seg.dtype == torch.uint8 else seg.to(torch.uint8)), img, params
+        return self._pipeline_f(image, segmentation, seeds, genparams, scale01, segmentation_u8, False)
+
+    def _pipeline_f(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None, labels_u8: bool = False):
         with _rng.use(self.rng):
             K._EPOCH[0] += 1
             arena = T.Arena()
@@ -807,7 +836,7 @@ class FetalSynthGen:
                 arena.upload(self.device)
             if fast:
                 try:
-                    native = self._run_native_fast(c, scale01)
+                    native = self._run_native_fast(c, scale01, labels_u8)
                 finally:
                     if arena.pending is not None:  # the native call was not reached: upload on the launch stream now
                         arena.flush(False)
@@ -820,7 +849,8 @@ class FetalSynthGen:
                     return native[0], native[1], None, self._synth_params(c, {})
             return self._run_stagewise(c, scale01)
 
-    def sample_batch(self, items, genparams_list=None, scale01: bool = False, streams: int = 1, lazy_items: int | None = None):
+    def sample_batch(self, items, genparams_list=None, scale01: bool = False, streams: int = 1, lazy_items: int | None = None,
+                     labels_u8: bool = False):
         """B samples with one parameter upload and one native call.
 
         items: sequence of (image | None, segmentation, seeds) as for `sample`; the host draws are made sample by sample
@@ -831,7 +861,8 @@ class FetalSynthGen:
         that many side streams (their kernel tails overlap); the current stream waits for all of them before returning.
         Samples outside the fused path's domain fall back to the per-sample path, with the draws already made.
         lazy_items=B: `items` is an iterator of B entries consumed one at a time, each right before that sample's host
-        draws (callers that re-seed the global generators per sample, e.g. PrefetchingStream)."""
+        draws (callers that re-seed the global generators per sample, e.g. PrefetchingStream).
+        labels_u8: the labels tensor as uint8 (same values), written as such by the fused warp."""
         import ctypes as C
 
         from .. import _lib
@@ -868,7 +899,7 @@ class FetalSynthGen:
                     with torch.cuda.stream(side[q]):
                         wss.append(self._workspace(shape, need))
                 out_all = torch.empty((B, *shape), dtype=torch.float32, device=dev)
-                seg_all = torch.empty((B, *shape), dtype=torch.float32, device=dev)
+                seg_all = torch.empty((B, *shape), dtype=torch.uint8 if labels_u8 else torch.float32, device=dev)
                 plans = (_lib.SamplePlan * B)()
                 ok = True
                 for b, c in enumerate(ctxs):
@@ -902,7 +933,8 @@ class FetalSynthGen:
                             else self._run_stagewise(c, scale01))
         same = len({tuple(o[0].shape) for o in outs}) == 1 if outs else False
         images = torch.stack([o[0] for o in outs]) if same else [o[0] for o in outs]
-        labels = torch.stack([o[1].float() for o in outs]) if same else [o[1] for o in outs]
+        ldt = torch.uint8 if labels_u8 else torch.float32
+        labels = torch.stack([o[1].to(ldt) for o in outs]) if same else [o[1].to(ldt) if labels_u8 else o[1] for o in outs]
         return images, labels, [o[2] for o in outs], [o[3] for o in outs]
 
     def _side_streams(self, n):

@@ -444,6 +444,9 @@ typedef struct fsg_sample_plan {
    * Results are those of overlap == 0. */
   int32_t overlap;
   uint64_t ws_seq;
+  /* optional: the deformed labels as uint8 (needs seg_in_u8; seg_out may then be NULL): the device-resident streaming hand-over
+   * (reference data/datasets.py:315-323 converts the labels after the fact) without a conversion pass */
+  uint8_t* seg_out_u8;
 } fsg_sample_plan;
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
 /* Layout check for FFI mirrors of the struct: which = 0 -> sizeof(fsg_sample_plan); 1 / 2 / 3 / 4 -> offsetof blur_taps / out /
@@ -466,7 +469,7 @@ enum {
   FSG_PLAN_I_NOISE_STREAM = 48, FSG_PLAN_I_SCALE01 = 49, FSG_PLAN_I_WS0 = 50, FSG_PLAN_I_WS1 = 51, FSG_PLAN_I_WS_LOW = 52,
   FSG_PLAN_I_WS_ROWS = 53, FSG_PLAN_I_ROW_STRIDE = 54, FSG_PLAN_I_MM8 = 55, FSG_PLAN_I_MM8_PRESET = 56, FSG_PLAN_I_OUT = 57,
   FSG_PLAN_I_EV_BEGIN = 58, FSG_PLAN_I_EV_END = 59, FSG_PLAN_I_MM_SLOTS = 60, FSG_PLAN_I_MM_NSLOTS = 61, FSG_PLAN_I_ARENA_HOST = 62,
-  FSG_PLAN_I_ARENA_DEV = 63, FSG_PLAN_I_ARENA_BYTES = 64, FSG_PLAN_I_OVERLAP = 65, FSG_PLAN_I_WS_SEQ = 66, FSG_PLAN_I_COUNT = 67
+  FSG_PLAN_I_ARENA_DEV = 63, FSG_PLAN_I_ARENA_BYTES = 64, FSG_PLAN_I_OVERLAP = 65, FSG_PLAN_I_WS_SEQ = 66, FSG_PLAN_I_SEG_OUT_U8 = 67, FSG_PLAN_I_COUNT = 68
 };
 enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_GAMMA = 15, FSG_PLAN_F_NOISE_STD = 16, FSG_PLAN_F_COUNT = 17 };
 #define FSG_PLAN_TAPS_STRIDE 132

@@ -1152,6 +1152,43 @@ def test_config4_384_hot_path_properties(K):
             assert abs(float(mean[l]) - float(mus[l])) < 0.05 and abs(float(var[l]) ** 0.5 - float(sig[l])) < 0.05
 
 
+@pytest.mark.parametrize("prob", [1.0, 0.5, 0.0])
+def test_uint8_label_output_equals_the_float_labels(K, prob):
+    """labels_u8=True (the device-resident stream's hand-over): the fused warp writes uint8 labels itself.  Same image bit
+    for bit, labels equal to the float32 ones, same generator states afterwards -- with every gate on, with gates failing
+    at random (no deformation: the labels pass through) and with all of them off."""
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (56, 48, 64)
+    seg, seeds = make_seed_volumes(shape, 1)
+    segd, bank = dev(seg), SeedBank(seeds, DEV)
+    gen = make_generator(shape, DEV, rng="device", prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.03, 0.12))
+    for i in range(6):
+        np.random.seed(40 + i)
+        torch.manual_seed(40 + i)
+        o1, l1, _, p1 = gen._pipeline(None, segd, bank, {}, scale01=True)
+        tail1 = (float(np.random.rand()), float(torch.rand(1)))
+        np.random.seed(40 + i)
+        torch.manual_seed(40 + i)
+        o2, l2, _, p2 = gen._pipeline(None, segd, bank, {}, scale01=True, labels_u8=True)
+        tail2 = (float(np.random.rand()), float(torch.rand(1)))
+        assert l2.dtype == torch.uint8 and l1.dtype == torch.float32
+        assert torch.equal(o1, o2) and torch.equal(l1, l2.float()) and tail1 == tail2
+        assert p1["resample_params"] == p2["resample_params"]
+    # the batched form
+    np.random.seed(77)
+    torch.manual_seed(77)
+    want = [gen._pipeline(None, segd, bank, {}, scale01=True) for _ in range(3)]
+    for streams in (1, 2):
+        np.random.seed(77)
+        torch.manual_seed(77)
+        out, lab, _, _ = gen.sample_batch([(None, segd, bank)] * 3, scale01=True, streams=streams, labels_u8=True)
+        assert lab.dtype == torch.uint8
+        for b in range(3):
+            assert torch.equal(out[b], want[b][0]) and torch.equal(lab[b].float(), want[b][1])
+
+
 @pytest.mark.parametrize("shape", [(64, 56, 72), (256, 256, 256)])
 def test_head_overlap_reproduces_the_in_order_stream(K, shape):
     """fsg_sample_plan::overlap: the parameter upload and the head of sample n+1 run on the library's side stream beside the
