@@ -195,7 +195,7 @@ class FetalSynthDataset(FetalDataset):
         t0 = time.time()
         gen_output, segmentation, image, synth_params = self.generator._pipeline(
             image, segm, seeds, genparams, scale01=True,
-            segmentation_u8=self._segmentation_u8(idx) if self.return_device else None)
+            segmentation_u8=self._segmentation_u8(idx) if self.return_device else None, labels_u8=self.return_device)
         if image is not None:
             from .. import kernels as K
 
@@ -224,11 +224,12 @@ class FetalSynthDataset(FetalDataset):
         names = [self._sub_ses_idx(i) for i in indices]
         t0 = time.time()
         items = [(None, self._segmentation(i), self._seeds_for(n)) for i, n in zip(indices, names)]
-        out, seg, _imgs, params = self.generator.sample_batch(items, genparams_list, scale01=True, streams=streams)
+        out, seg, _imgs, params = self.generator.sample_batch(items, genparams_list, scale01=True, streams=streams,
+                                                              labels_u8=self.return_device)
         if not torch.is_tensor(out):
             raise ValueError("sample_batch needs subjects of one shape")
         if self.return_device:
-            image, label = out.unsqueeze(1), seg.to(torch.uint8).unsqueeze(1)
+            image, label = out.unsqueeze(1), seg.unsqueeze(1)
         else:
             image, label = out.cpu().unsqueeze(1), seg.cpu().long().unsqueeze(1)
         dt = time.time() - t0

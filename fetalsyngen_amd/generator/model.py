@@ -254,9 +254,11 @@ class FetalSynthGen:
             cache[key] = hit
         return hit[0]
 
-    def _native_ok(self, c) -> bool:
+    def _native_ok(self, c, labels_u8: bool = False) -> bool:
+        """labels_u8: the caller wants uint8 labels -- the fused path then writes them itself and a caller-supplied uint8
+        copy of the segmentation (the stage-by-stage path's way to uint8 labels) does not keep the sample off it."""
         return (self.native_pipeline and c.label_parts is not None and c.image is None and not c.has_art
-                and c.segmentation_u8 is None)
+                and (c.segmentation_u8 is None or labels_u8))
 
     def _native_operands(self, c):
         """Shape / dtype / device checks of everything the C side only sees as pointers (a mismatched volume would make
@@ -831,7 +833,7 @@ class FetalSynthGen:
                 nxt[akey] = torch.empty(_ARENA_BLOCK, dtype=torch.uint8, device=dev)
             c = self._prepare(image, segmentation, seeds, genparams, arena, segmentation_u8)
             c.arena_early = early
-            fast = self._native_ok(c) and not _SLOW_PLAN
+            fast = self._native_ok(c, labels_u8) and not _SLOW_PLAN
             if not (fast and block is not None and arena.stage(self.device, block)):
                 arena.upload(self.device)
             if fast:
@@ -843,7 +845,7 @@ class FetalSynthGen:
                 if native is not None:
                     return native[0], native[1], None, self._synth_params(c, {})
             self._resolve(c)
-            if self._native_ok(c):
+            if self._native_ok(c, labels_u8):
                 native = self._run_native(c, scale01)
                 if native is not None:
                     return native[0], native[1], None, self._synth_params(c, {})
