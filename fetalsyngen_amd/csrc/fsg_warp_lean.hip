@@ -17,7 +17,7 @@
 //     last plane / row) that neighbour's weight is exactly 0, so the finite value (or the 0 of an out-of-range
 //     read) found there contributes +-0;
 //   * the axis-0 flip is folded into a signed plane stride and a base offset (no per-voxel select);
-//   * index products on v_mad_i32_i24 (full rate) instead of v_mul_lo_u32 (quarter rate);
+//   * index products on v_mul_i32_i24 / v_mad_i32_i24;
 //   * work shape: the 16 waves of a workgroup sweep 8 x 4 adjacent rows, 32 voxels of each per lockstep step
 //     (fsg_warp_set_variant 3 of the patch kernel family, the fastest of the shapes measured).
 // Domain (else FSG_E_ALIGN and the caller falls back): per-row coarse values precomputed (fsg_deform_rows_f32),
