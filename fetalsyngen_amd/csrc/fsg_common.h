@@ -115,14 +115,19 @@ __device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, 
                                                 uint64_t seed, uint64_t stream_id, float* __restrict__ out, unsigned blk,
                                                 unsigned nblk) {
   const size_t ngrp = (n + 3) >> 2;
+  // The four label words of a group are requested TOGETHER: with `if (l1) w += *l1` the compiler put each load, its wait and
+  // its add into a branch of their own -- four dependent round trips to memory per group, and the kernel ran at that latency
+  // (36 us) whatever the arithmetic did; the same draw with the loads issued back to back is memory bound at 21 us
+  // (tools/ubench/stream_shapes.hip, profiles/r02_j_gmm_head.txt).  An absent volume reads l0 again under a zero mask.
+  const uint8_t *p1 = l1 ? l1 : l0, *p2 = l2 ? l2 : l0, *p3 = l3 ? l3 : l0;
+  const uint32_t m1 = l1 ? 0xFFFFFFFFu : 0u, m2 = l2 ? 0xFFFFFFFFu : 0u, m3 = l3 ? 0xFFFFFFFFu : 0u;
   for (size_t g = (size_t)blk * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)nblk * blockDim.x) {
     const size_t e = g << 2;
     uint32_t w = 0;
     if (e + 3 < n) {
-      w = *reinterpret_cast<const uint32_t*>(l0 + e);
-      if (l1) w += *reinterpret_cast<const uint32_t*>(l1 + e);
-      if (l2) w += *reinterpret_cast<const uint32_t*>(l2 + e);
-      if (l3) w += *reinterpret_cast<const uint32_t*>(l3 + e);
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(l0 + e), w1 = *reinterpret_cast<const uint32_t*>(p1 + e);
+      const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p2 + e), w3 = *reinterpret_cast<const uint32_t*>(p3 + e);
+      w = w0 + (w1 & m1) + (w2 & m2) + (w3 & m3);
     } else {
       for (int q = 0; q < 4 && e + q < n; ++q) {
         uint32_t b = l0[e + q];
