@@ -786,10 +786,20 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   // row kernel's 2 048 (38 vs 31 us; 22 us with the atomics removed) whether or not the keys are sharded over slots
   if (((!noise_epi && (EPI != EPI_MINMAX || E.mm_shards > 1)) || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
       !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_TILE_ZOOM))) {
-    int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
+    // tile height: the kernel's fixed part per workgroup (taps, window bounds, x stage: a chain of global round trips) costs
+    // 10-12 us of its 19-27 us at 16 rows per tile (profiles/r02_b_zoom_experiments.txt, ablation).  Twice the rows per
+    // workgroup pays for the pass that stores nothing (K9a 19.0 -> 17.3 us); the storing passes lose it again (27.4 -> 28.5)
+    const int ty_pref = EPI == EPI_MINMAX ? 2 * g_zoom_ty : g_zoom_ty;
+    int TY = ty_pref < ZT_MAX_TY ? ty_pref : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;
-    const long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-    const long long total = est + 4LL * Z.sz;  // window + the four waves' rows
+    long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
+    long long total = est + 4LL * Z.sz;  // window + the four waves' rows
+    if (!(est <= g_zoom_cap && total <= 16000)) {
+      TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
+      if (TY > Z.dy) TY = Z.dy;
+      est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
+      total = est + 4LL * Z.sz;
+    }
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;
       hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), (size_t)total * sizeof(float),
