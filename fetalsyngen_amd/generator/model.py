@@ -310,7 +310,7 @@ class FetalSynthGen:
             tb = np.zeros((3, self._TAPS_STRIDE), dtype=np.float32)
             centre = (np.array(self.spatial_deform.size) - 1) / 2
             fb = self._flat = dict(iv=iv, fv=fv, tb=tb, ivp=iv.ctypes.data, fvp=fv.ctypes.data, tbp=tb.ctypes.data,
-                                   centre=np.asarray(centre, dtype=np.float32).tolist(), validated=set())
+                                   centre=np.asarray(centre, dtype=np.float32).tolist(), validated={})
         return fb
 
     def _flat_plan(self, c, scale01, out, seg_out, ws, events=None):
@@ -434,17 +434,27 @@ class FetalSynthGen:
         if not (torch.is_tensor(seg) and seg.is_cuda and seg.dtype == torch.float32 and seg.is_contiguous()):
             return False
         fb = self._flat_buffers()
-        key = (seg.data_ptr(), tuple(seg.shape)) + tuple(p.data_ptr() for p in c.label_parts)
-        if key not in fb["validated"]:
+        # Every tensor is checked once, as an object (id + weak reference: a new tensor at a recycled address is a new object)
+        # together with the sample shape it was checked against.  Per TENSOR, not per combination: the seed volumes of a subject
+        # combine in up to 6^4 ways, and a per-combination cache missed on most samples of a run.
+        val = fb["validated"]
+        shape = c.shape = tuple(int(v) for v in c.shape)
+        known = True
+        for t_ in (seg, *c.label_parts):
+            hit = val.get(id(t_))
+            if hit is None or hit[0]() is not t_ or hit[1] != shape:
+                known = False
+                break
+        if not known:
             c.mus, c.sigmas = (c.arena.f32(c.gm_off[0], (c.gm_off[2],)), c.arena.f32(c.gm_off[1], (c.gm_off[2],)))
             self._native_operands(c)  # raises on a mismatch
             if c.seg is not seg:
                 return False
-            if len(fb["validated"]) > 4096:
-                fb["validated"].clear()
-            fb["validated"].add(key)
+            if len(val) > 4096:
+                val.clear()
+            for t_ in (seg, *c.label_parts):
+                val[id(t_)] = (weakref.ref(t_), shape)
         c.seg = seg
-        c.shape = tuple(int(v) for v in c.shape)
         if c.gm_off[2] > 256 or c.gm_off[2] < 1:
             raise ValueError(f"mus / sigmas tables of {c.gm_off[2]} entries (need 1..256)")
         return True
