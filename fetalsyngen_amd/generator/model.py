@@ -788,7 +788,14 @@ class FetalSynthGen:
             c.bias_off = arena.add(bplan.grid.numpy())
         c.rs_tabs = c.back_tabs = None
         if rplan.active:
-            c.rs_tabs = K.DeviceTables(rplan.tabs, dev, arena)
+            # the three per-axis tables depend on (low-res size, size) only: one DeviceTables object per pair
+            rs_cache = self.__dict__.setdefault("_rs_dt", {})
+            rs_key = (tuple(rplan.new_size), shape)
+            c.rs_tabs = rs_cache.get(rs_key)
+            if c.rs_tabs is None:
+                if len(rs_cache) > 4096:
+                    rs_cache.clear()
+                c.rs_tabs = rs_cache[rs_key] = K.DeviceTables(rplan.tabs, dev, arena)
             # zoom-back by 1 / factors, factors = new_size / size (tables.resample_plan): a function of the two shapes
             bt, new = T.zoom_tables_between(tuple(rplan.new_size), shape, True)
             c.back_tabs = K.device_tables_for(bt, dev)
