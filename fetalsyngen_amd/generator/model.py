@@ -25,9 +25,11 @@ import torch
 from .. import kernels as K
 from .. import rng as _rng
 from .. import tables as T
-from .augmentation.synthseg import RandBiasField, RandGamma, RandNoise, RandResample
-from .deformation.affine_nonrigid import SpatialDeformation
-from .intensity.rand_gmm import ImageFromSeeds
+from .. import _lib
+from ..utils.generation import make_affine_matrix
+from .augmentation.synthseg import BiasPlan, NoisePlan, RandBiasField, RandGamma, RandNoise, RandResample, ResamplePlan
+from .deformation.affine_nonrigid import DeformPlan, SpatialDeformation
+from .intensity.rand_gmm import GMMPlan, ImageFromSeeds
 
 
 # [+inf x4 | -inf x4] as the order-preserving int32 keys of fsg_minmax_init (csrc/fsg_common.h: fsg_f2key)
@@ -176,7 +178,6 @@ class FetalSynthGen:
         configuration is outside the fused kernels' domain (blur radius beyond the plan's tap capacity)."""
         import ctypes as C
 
-        from .. import _lib
 
         dev = torch.device(self.device)
         shape, seg, spec, rplan, nplan = c.shape, c.seg, c.spec, c.rplan, c.nplan
@@ -462,7 +463,6 @@ class FetalSynthGen:
     def _run_native_fast(self, c, scale01, labels_u8=False):
         """Prepared sample -> (image, labels) through fsg_sample_pack_run, or None (caller falls back).  labels_u8: the labels
         as a uint8 volume (written by the warp itself; without a deformation the cached uint8 copy of the input)."""
-        from .. import _lib
 
         if not self._fast_operands(c):
             return None
@@ -511,7 +511,6 @@ class FetalSynthGen:
         configuration is outside the fused kernels' domain (the caller then launches stage by stage)."""
         import ctypes as C
 
-        from .. import _lib
 
         dev = torch.device(self.device)
         self._native_operands(c)
@@ -642,10 +641,6 @@ class FetalSynthGen:
         between two gates are fetched in one call (gates still short-circuit: nothing behind a failed gate is drawn);
         `torch.rand(2n)` equals two `torch.rand(n)`.  Scalars are combined as Python floats (the same IEEE doubles as the
         0-d numpy arithmetic of the per-stage code)."""
-        from .augmentation.synthseg import BiasPlan, NoisePlan, ResamplePlan
-        from .deformation.affine_nonrigid import DeformPlan
-        from .intensity.rand_gmm import GMMPlan
-        from ..utils.generation import make_affine_matrix
 
         ig, sd, bf, rs_, nz, gm = (self.intensity_generator, self.spatial_deform, self.biasfield, self.resampled, self.noise,
                                    self.gamma)
@@ -884,7 +879,6 @@ class FetalSynthGen:
         labels_u8: the labels tensor as uint8 (same values), written as such by the fused warp."""
         import ctypes as C
 
-        from .. import _lib
 
         if lazy_items is None:
             items = list(items)

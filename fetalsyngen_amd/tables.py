@@ -19,6 +19,8 @@ import threading
 import numpy as np
 import torch
 
+from . import _lib
+
 TAP_DTYPE = np.dtype([("lo", "<i4"), ("hi", "<i4"), ("w_lo", "<f4"), ("w_hi", "<f4")])
 
 
@@ -210,8 +212,6 @@ class Arena:
         if ring is not None:
             # copy *kernel* on the launch stream from a device-visible pinned slot: the sample stays in one hardware queue
             # (a memcpy command between the previous sample's kernels and this one's costs ~10 us of queue hand-over)
-            from . import _lib
-
             slot, host = ring.acquire()
             hv = host.numpy()
             for off, arr in self._items:
@@ -260,8 +260,6 @@ class Arena:
         ring, slot, host_ptr, n = self.pending
         self.pending = None
         if not copied:
-            from . import _lib
-
             _lib.check(_lib.load().fsg_copy_bytes(self.dev.data_ptr(), host_ptr, n, ring.raw_stream()), "fsg_copy_bytes")
         ring.release(slot)
 
