@@ -766,7 +766,10 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   const int rows = Z.dx * Z.dy;
   // measured at 256^3: the tile kernel wins where the Philox epilogue dominates (down-sampling + noise, K7: 27 vs 33 us
   // at m = 171, 42 vs 68 us at m = 256); the row kernels stay ahead for the up-sampling passes of K9 (30 vs 35-38 us)
-  if ((EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR || (g_tuning_flags & FSG_TUNE_TILE_ZOOM)) &&
+  // K7 at large low-res sizes: the slab kernel is ahead from ~200 outputs per row on (m = 220: 32 vs 41 us, m = 256: 39 vs 47 us;
+  // m = 171: 36 vs 27, m = 128: 20 vs 18 -- profiles/r02_b_zoom_experiments.txt), so the noise epilogues switch there
+  const bool noise_big = (EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR) && Z.dz >= 196 && Z.sz <= 256 && Z.dz <= 256;
+  if ((EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR || (g_tuning_flags & FSG_TUNE_TILE_ZOOM)) && !noise_big &&
       !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_SLAB_ZOOM))) {
     // window estimate for the tile kernel: TY rows advance sy/dy source rows each (+2 for the pair and rounding)
     int TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
@@ -784,7 +787,7 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   // measured at 256^3 (profiles/r02_b_zoom_experiments.txt): the slab kernel wins for the passes that store (K9b 28 vs 32.5 us);
   // the min/max pass ends every workgroup with two gated atomics, which cost the slab kernel's 4 096 workgroups more than the
   // row kernel's 2 048 (38 vs 31 us; 22 us with the atomics removed) whether or not the keys are sharded over slots
-  if (((!noise_epi && (EPI != EPI_MINMAX || E.mm_shards > 1)) || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
+  if (((!noise_epi && (EPI != EPI_MINMAX || E.mm_shards > 1)) || noise_big || (g_tuning_flags & FSG_TUNE_SLAB_ZOOM)) &&
       !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_TILE_ZOOM))) {
     // tile height: the kernel's fixed part per workgroup (taps, window bounds, x stage: a chain of global round trips) costs
     // 10-12 us of its 19-27 us at 16 rows per tile (profiles/r02_b_zoom_experiments.txt, ablation).  Twice the rows per
