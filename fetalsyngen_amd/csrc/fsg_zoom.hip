@@ -768,7 +768,10 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
   // at m = 171, 42 vs 68 us at m = 256); the row kernels stay ahead for the up-sampling passes of K9 (30 vs 35-38 us)
   // K7 at large low-res sizes: the slab kernel is ahead from ~200 outputs per row on (m = 220: 32 vs 41 us, m = 256: 39 vs 47 us;
   // m = 171: 36 vs 27, m = 128: 20 vs 18 -- profiles/r02_b_zoom_experiments.txt), so the noise epilogues switch there
-  const bool noise_big = (EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR) && Z.dz >= 196 && Z.sz <= 256 && Z.dz <= 256;
+  // (only for row lengths that are a multiple of 4: the slab kernel draws one Philox block per aligned quad of the OUTPUT
+  // index, which needs every row to start on a multiple of 4 -- otherwise it draws per element, 45-55 us: tools/k7_sweep.py)
+  const bool noise_big = (EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR) && Z.dz >= 196 && (Z.dz & 3) == 0 && Z.sz <= 256 &&
+                         Z.dz <= 256;
   if ((EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR || (g_tuning_flags & FSG_TUNE_TILE_ZOOM)) && !noise_big &&
       !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_SLAB_ZOOM))) {
     // window estimate for the tile kernel: TY rows advance sy/dy source rows each (+2 for the pair and rounding)
