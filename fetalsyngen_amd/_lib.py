@@ -13,6 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("FSG_LIB", PKG / "libfsg_hip.so"))  # FSG_LIB: A/B another build of the same ABI
 
 E_BADARG, E_TOOBIG, E_ALIGN = -1, -2, -3
+ABI_VERSION = 2  # include/fsg_hip.h: FSG_ABI_VERSION
 
 
 class FsgError(RuntimeError):
@@ -168,6 +169,7 @@ SIGNATURES = {
     "fsg_sample_pack_run": [P, I, P, I, P, P],
     "fsg_sample_run_batch": [C.POINTER(SamplePlan), I, C.POINTER(C.c_void_p), I],
     "fsg_cast_f32_to_f16": [P, SZ, P, P],
+    "fsg_pipeline_teardown": [],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
 }
@@ -196,8 +198,12 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
-    if lib.fsg_abi_version() != 1:
-        raise RuntimeError("libfsg_hip.so ABI version mismatch")
+    if lib.fsg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libfsg_hip.so ABI version {lib.fsg_abi_version()}, this binding expects {ABI_VERSION}")
+    # the structs cross the boundary by pointer: a mirror that disagrees on their size would have the library read past its end
+    if lib.fsg_sample_plan_layout(0) != C.sizeof(SamplePlan):
+        raise RuntimeError(f"fsg_sample_plan is {lib.fsg_sample_plan_layout(0)} bytes in libfsg_hip.so, "
+                           f"{C.sizeof(SamplePlan)} in the ctypes mirror")
     _lib = lib
     return lib
 

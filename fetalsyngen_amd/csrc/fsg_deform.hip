@@ -1500,7 +1500,11 @@ extern int g_lean_pace, g_lean_ablate;
 int fsg_warp_set_variant(int variant) {
   const int prev = g_warp_variant;
   g_lean_ablate = 0;
+#ifdef FSG_DIAG  // the ablation kernels (wrong results by construction) exist in a -DFSG_DIAG build only
   if (variant == 8 || variant == 9) { g_warp_variant = 0; g_lean_pace = 1; g_lean_ablate = variant - 7; }
+#else
+  if (variant == 8 || variant == 9) return FSG_E_BADARG;
+#endif
   if (variant >= 0 && variant <= 4) { g_warp_variant = variant; g_lean_pace = -1; }
   if (variant >= 5 && variant <= 7) { g_warp_variant = 0; g_lean_pace = variant == 5 ? 0 : (variant == 6 ? 2 : 1); }
   return prev;

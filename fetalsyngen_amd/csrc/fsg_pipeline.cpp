@@ -6,6 +6,7 @@
 // interpreter between launches costs as much as the kernels; semantics and results are those of calling the
 // entry points one by one (tests/test_hip_parity.py::test_native_pipeline_equals_stagewise).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstddef>
 #include <map>
 #include <mutex>
@@ -27,31 +28,60 @@ struct HeadOverlap {
   uint64_t seq = 0;
   const float* ws0 = nullptr;
 };
+// g_ho_mu guards the map AND every field of its entries: fsg_sample_run holds it from the look-up to its last access of the
+// entry whenever the overlap state is involved (two host threads launching on one (device, stream) pair serialise there;
+// without the overlap the lock is taken once, briefly, to invalidate a stale entry).
 std::mutex g_ho_mu;
 std::map<std::pair<int, hipStream_t>, HeadOverlap> g_ho;
+std::atomic<bool> g_ho_used{false};  // no entry was ever created: the default path never takes the lock
 
-HeadOverlap* head_overlap_state(hipStream_t st, bool create) {
+// Caller holds g_ho_mu.  `err` receives the HIP error of a failed creation (partially created objects are destroyed).
+HeadOverlap* head_overlap_state(hipStream_t st, bool create, hipError_t* err) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(g_ho_mu);
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { if (err) *err = e; return nullptr; }
   auto key = std::make_pair(dev, st);
   auto it = g_ho.find(key);
   if (it != g_ho.end()) return &it->second;
   if (!create) return nullptr;
   HeadOverlap h;
-  if (hipStreamCreateWithFlags(&h.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&h.ev_free, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h.ev_head, hipEventDisableTiming) != hipSuccess) {
+  if ((e = hipStreamCreateWithFlags(&h.side, hipStreamNonBlocking)) != hipSuccess) { if (err) *err = e; return nullptr; }
+  if ((e = hipEventCreateWithFlags(&h.ev_free, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&h.ev_head, hipEventDisableTiming)) != hipSuccess) {
+    if (h.ev_free) (void)hipEventDestroy(h.ev_free);
+    (void)hipStreamDestroy(h.side);
+    if (err) *err = e;
     return nullptr;
   }
   return &g_ho.emplace(key, h).first->second;  // std::map: the address stays valid
 }
 }  // namespace
 
+// Releases the side streams and events of the head overlap (they otherwise live for the life of the process).  The caller
+// must have synchronised the streams it launched samples on.
+extern "C" int fsg_pipeline_teardown(void) {
+  std::lock_guard<std::mutex> lk(g_ho_mu);
+  int rc = 0;
+  for (auto& kv : g_ho) {
+    HeadOverlap& h = kv.second;
+    hipError_t e;
+    if (h.ev_free && (e = hipEventDestroy(h.ev_free)) != hipSuccess) rc = (int)e;
+    if (h.ev_head && (e = hipEventDestroy(h.ev_head)) != hipSuccess) rc = (int)e;
+    if (h.side && (e = hipStreamDestroy(h.side)) != hipSuccess) rc = (int)e;
+  }
+  g_ho.clear();
+  return rc;
+}
+
 #define FSG_TRY(expr)        \
   do {                       \
     int rc_ = (expr);        \
     if (rc_ != 0) return rc_; \
+  } while (0)
+#define FSG_HIP(expr)                          \
+  do {                                         \
+    hipError_t e_ = (expr);                    \
+    if (e_ != hipSuccess) return (int)e_;      \
   } while (0)
 
 extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
@@ -70,17 +100,27 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
                           need_h > 0 && need_h <= p->row_stride;
   // where the upload and the head go: the side stream when the caller asked for the overlap and the head is one launch
   HeadOverlap* ho = nullptr;
-  if (p->overlap && fused_head && p->resample_active && p->arena_host) ho = head_overlap_state(st, true);
-  if (!ho) {  // this call uses the workspace in launch-stream order only: a later overlapped call must not trust an old event
-    HeadOverlap* old = head_overlap_state(st, false);
-    if (old) old->has_free = false;
+  std::unique_lock<std::mutex> ho_lock(g_ho_mu, std::defer_lock);
+  const bool want_overlap = p->overlap && fused_head && p->resample_active && p->arena_host;
+  if (want_overlap || g_ho_used.load(std::memory_order_acquire)) {
+    ho_lock.lock();
+    if (want_overlap) {
+      hipError_t herr = hipSuccess;
+      ho = head_overlap_state(st, true, &herr);
+      if (!ho) return herr != hipSuccess ? (int)herr : FSG_E_BADARG;
+      g_ho_used.store(true, std::memory_order_release);
+    } else {  // this call uses the workspace in launch-stream order only: a later overlapped call must not trust an old event
+      HeadOverlap* old = head_overlap_state(st, false, nullptr);
+      if (old) old->has_free = false;
+      ho_lock.unlock();
+    }
   }
   void* hstream = stream;
-  if (ho) {
+  if (ho) {  // ho_lock is held until this call returns
     if (!(ho->has_free && ho->ws0 == p->ws0 && ho->seq + 1 == p->ws_seq)) {
-      if (hipEventRecord(ho->ev_free, st) != hipSuccess) return FSG_E_BADARG;  // behind everything enqueued so far
+      FSG_HIP(hipEventRecord(ho->ev_free, st));  // behind everything enqueued so far
     }
-    if (hipStreamWaitEvent(ho->side, ho->ev_free, 0) != hipSuccess) return FSG_E_BADARG;
+    FSG_HIP(hipStreamWaitEvent(ho->side, ho->ev_free, 0));
     ho->has_free = false;
     hstream = (void*)ho->side;
   }
@@ -99,8 +139,8 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     if (head_rc == 0) head_done = true;
   }
   if (ho) {  // whatever happened on the side stream is ordered before the rest of the sample (and before any fallback)
-    if (hipEventRecord(ho->ev_head, ho->side) != hipSuccess || hipStreamWaitEvent(st, ho->ev_head, 0) != hipSuccess)
-      return FSG_E_BADARG;
+    FSG_HIP(hipEventRecord(ho->ev_head, ho->side));
+    FSG_HIP(hipStreamWaitEvent(st, ho->ev_head, 0));
   }
   if (head_rc != 0 && head_rc != FSG_E_TOOBIG && head_rc != FSG_E_ALIGN) return head_rc;
   // K1: GMM draw -> ws0; the same launch resets every min/max key of the sample (unless they arrived initialised):
@@ -188,7 +228,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     const int m0 = p->low_shape[0], m1 = p->low_shape[1], m2 = p->low_shape[2];
     auto mark_free = [&]() -> int {  // from here on this call touches neither ws0 nor ws_rows
       if (!ho) return 0;
-      if (hipEventRecord(ho->ev_free, st) != hipSuccess) return FSG_E_BADARG;
+      FSG_HIP(hipEventRecord(ho->ev_free, st));
       ho->has_free = true;
       ho->seq = p->ws_seq;
       ho->ws0 = p->ws0;

@@ -244,7 +244,8 @@ int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const fl
 #define FSG_LEAN(L, N, F) \
   hipLaunchKernelGGL((warp_lean_kernel<ST, DT, L, N, F, KZ, WI>), grid, block, 0, st, D, mm6, src_lin, out_lin, src_nn, out_nn, E, \
                      pace)
-  if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {  // diagnostic instantiations (tools/kernel_bench.py --variant 8 / 9)
+#ifdef FSG_DIAG  // ablation instantiations (results are wrong; tools/kernel_bench.py --variant 8 / 9 on a -DFSG_DIAG build)
+  if (src_lin && src_nn && fast && g_lean_ablate && sizeof(ST) == 4 && sizeof(DT) == 4) {
     if (g_lean_ablate == 1)
       hipLaunchKernelGGL((warp_lean_kernel<ST, DT, true, true, true, KZ, WI, 1>), grid, block, 0, st, D, mm6, src_lin, out_lin,
                          src_nn, out_nn, E, pace);
@@ -253,6 +254,7 @@ int launch_lean(const FsgDeformK& D, const EpiK& E, const int32_t* mm6, const fl
                          src_nn, out_nn, E, pace);
     FSG_RETURN_LAUNCH();
   }
+#endif
   if (src_lin && src_nn) { if (fast) FSG_LEAN(true, true, true); else FSG_LEAN(true, true, false); }
   else if (src_lin)      { if (fast) FSG_LEAN(true, false, true); else FSG_LEAN(true, false, false); }
   else                   { FSG_LEAN(false, true, true); }

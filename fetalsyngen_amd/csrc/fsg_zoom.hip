@@ -743,7 +743,11 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
     hi = fsg_wave_max(hi);
     if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
     __syncthreads();
+#ifdef FSG_DIAG
     if (tid == 0 && E.norm_mode != 77) {
+#else
+    if (tid == 0) {
+#endif
       for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
       zoom_mm_update(E, lo, hi);
     }
@@ -884,7 +888,9 @@ int fsg_zoom3d_minmax_f32(const float* src, int sx, int sy, int sz, const fsg_ta
   EpiZ E{};
   E.mm_out = mm;
   E.mm_shards = 1;
-  if (getenv("FSG_DIAG_NO_MM_ATOMICS")) E.norm_mode = 77;  // DIAGNOSTIC (timing only): results are wrong
+#ifdef FSG_DIAG  // timing ablation (results are wrong): only in a -DFSG_DIAG build, never in the shipped library
+  if (getenv("FSG_DIAG_NO_MM_ATOMICS")) E.norm_mode = 77;
+#endif
   return launch1<EPI_MINMAX>(Z, E, stream);
 }
 

@@ -25,19 +25,46 @@ from ..utils.image_reading import NiftiReader
 
 
 class SeedBank:
-    """Per-subject decoded seed volumes, device resident (uint8), combined on demand."""
+    """Per-subject decoded seed volumes, device resident (uint8), combined on demand.
+
+    Pickling (DataLoader workers, reference fetalsyngen/test_dl.py:17-24): the state that travels is the HOST copy of the
+    volumes (uint8 numpy arrays) and the device string; the worker uploads them on first use.  No device tensor, no
+    address of the parent process crosses the process boundary."""
 
     def __init__(self, volumes: dict, device):
         self.device = device
-        self.vol = {
+        self._host = None
+        self._vol = {
             n: {m: torch.as_tensor(np.asarray(v)).to(torch.uint8).to(device) for m, v in d.items()}
             for n, d in volumes.items()
         }
         self._cache = {}
 
+    @property
+    def vol(self):
+        if self._vol is None:  # unpickled in another process: upload now
+            self._vol = {n: {m: torch.from_numpy(v).to(self.device) for m, v in d.items()} for n, d in self._host.items()}
+            self._host = None
+        return self._vol
+
+    def __getstate__(self):
+        host = self._host
+        if host is None:
+            host = {n: {m: v.cpu().numpy() for m, v in d.items()} for n, d in self._vol.items()}
+        return {"device": self.device, "host": host}
+
+    def __setstate__(self, state):
+        self.device, self._host, self._vol, self._cache = state["device"], state["host"], None, {}
+
+    @property
+    def nbytes(self) -> int:
+        src = self._vol if self._vol is not None else self._host
+        return sum(int(np.prod(v.shape)) for d in src.values() for v in d.values())
+
     def parts(self, mlabel2subclusters: dict):
         """The selected per-meta-label volumes (disjoint supports); `fsg_gmm_sample_u8x4` sums them on the fly."""
-        return [self.vol[n][m] for m, n in sorted(mlabel2subclusters.items())]
+        vol = self._vol if self._vol is not None else self.vol
+        return [vol[n][m] for m, n in sorted(mlabel2subclusters.items())]
 
     @property
     def shape(self):
@@ -48,7 +75,8 @@ class SeedBank:
         more distinct synthetic subjects)."""
         other = SeedBank.__new__(SeedBank)
         other.device = self.device
-        other.vol = {n: {m: fn(v).contiguous() for m, v in d.items()} for n, d in self.vol.items()}
+        other._host = None
+        other._vol = {n: {m: fn(v).contiguous() for m, v in d.items()} for n, d in self.vol.items()}
         other._cache = {}
         return other
 
@@ -64,6 +92,68 @@ class SeedBank:
                 self._cache.pop(next(iter(self._cache)))
             self._cache[key] = hit
         return hit
+
+
+class LabelCache:
+    """Byte-budgeted LRU of device-resident label volumes (per subject: the seed bank, the float32 segmentation and its
+    uint8 twin -- 464 MiB at 256^3 with 6 x 4 seed volumes).
+
+    The reference keeps nothing: it re-reads and gunzips five NIfTI files per sample (data/datasets.py:280-296,
+    rand_gmm.py:82-99).  Here a subject's decoded volumes stay in HBM until the budget is exceeded; then the least recently
+    used subjects are dropped and re-read from their files when they come up again (same values: the files are the source).
+    `budget_bytes=None`: half of the HBM that is free when the first subject is inserted.  The most recent entry is never
+    evicted (a budget smaller than one subject degrades to the reference's read-per-sample behaviour, not to an error).
+
+    Eviction and in-flight kernels: the host runs several samples ahead of the GPU, so kernels already enqueued may still
+    read an evicted volume.  Eviction happens only on a miss, i.e. next to tens of milliseconds of file decoding, so it
+    simply waits for the device to drain (`torch.cuda.synchronize`) before the references are dropped -- stronger than
+    `record_stream` marks and free of per-sample cost."""
+
+    def __init__(self, device, budget_bytes: int | None = None, fraction: float = 0.5):
+        from collections import OrderedDict
+
+        self.device, self.budget_bytes, self.fraction = device, budget_bytes, fraction
+        self.entries = OrderedDict()  # key -> (value, nbytes)
+        self.bytes, self.hits, self.misses, self.evictions = 0, 0, 0, 0
+
+    def __getstate__(self):  # a worker process starts with an empty cache of the same budget
+        return {"device": self.device, "budget_bytes": self.budget_bytes, "fraction": self.fraction}
+
+    def __setstate__(self, state):
+        self.__init__(state["device"], state["budget_bytes"], state["fraction"])
+
+    def __contains__(self, key):
+        return key in self.entries
+
+    def __len__(self):
+        return len(self.entries)
+
+    def peek(self, key):
+        hit = self.entries.get(key)
+        return None if hit is None else hit[0]
+
+    def get(self, key, build):
+        """The cached value of `key`, or `build() -> (value, nbytes)` inserted as the most recent entry."""
+        hit = self.entries.get(key)
+        if hit is not None:
+            self.hits += 1
+            self.entries.move_to_end(key)
+            return hit[0]
+        self.misses += 1
+        value, nbytes = build()
+        if self.budget_bytes is None:
+            free = torch.cuda.mem_get_info(torch.device(self.device))[0] if torch.cuda.is_available() else (1 << 62)
+            self.budget_bytes = int((free + nbytes) * self.fraction)
+        self.entries[key] = (value, int(nbytes))
+        self.bytes += int(nbytes)
+        if self.bytes > self.budget_bytes and len(self.entries) > 1:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(torch.device(self.device))  # kernels in flight may still read what goes now
+            while self.bytes > self.budget_bytes and len(self.entries) > 1:
+                _k, (_v, nb) = self.entries.popitem(last=False)
+                self.bytes -= nb
+                self.evictions += 1
+        return value
 
 
 class FetalDataset:
@@ -128,7 +218,14 @@ class FetalSynthDataset(FetalDataset):
         image_as_intensity: bool = False,
         cache_on_device: bool = True,
         return_device: bool = False,
+        cache_bytes: int | None = None,
+        base_seed: int | None = None,
     ):
+        """`cache_bytes`: HBM budget of the decoded-label cache (`LabelCache`; None = half of the free HBM).
+        `base_seed`: None keeps the reference's behaviour (`__getitem__` draws from the global generators as they stand);
+        an integer makes `__getitem__(idx)` re-seed numpy's and torch's CPU generators with the key
+        `(base_seed, epoch * len(self) + idx)` first (`sharding.seed_for_sample`), so a sample depends on its index only --
+        not on which DataLoader worker produced it, nor on how many workers there are (`set_epoch` moves to fresh keys)."""
         super().__init__(bids_path, sub_list)
         self.seed_path = Path(seed_path) if isinstance(seed_path, str) else None
         self.load_image = load_image
@@ -136,7 +233,8 @@ class FetalSynthDataset(FetalDataset):
         self.image_as_intensity = image_as_intensity
         self.cache_on_device = cache_on_device
         self.return_device = return_device
-        self._banks, self._segs = {}, {}
+        self.base_seed, self.epoch = base_seed, 0
+        self._labels = LabelCache(generator.device, cache_bytes)
         if not self.image_as_intensity and isinstance(self.seed_path, Path):
             if not self.seed_path.exists():
                 raise FileNotFoundError(f"Provided seed path {self.seed_path} does not exist.")
@@ -154,38 +252,63 @@ class FetalSynthDataset(FetalDataset):
                 for (s, ses), f in zip(self.sub_ses, files):
                     self.seed_paths[self._sub_ses_string(s, ses)][n_sub][m] = f
 
-    def _seeds_for(self, name):
-        if not self.cache_on_device:
-            return self.seed_paths[name]
-        if name not in self._banks:
-            vols = {n: {m: self.loader(p).numpy() for m, p in d.items()} for n, d in self.seed_paths[name].items()}
-            self._banks[name] = SeedBank(vols, self.generator.device)
-        return self._banks[name]
+    def set_epoch(self, epoch: int):
+        """With `base_seed`: sample keys become (base_seed, epoch * len(self) + idx)."""
+        self.epoch = int(epoch)
 
-    def _segmentation(self, idx):
-        if not self.cache_on_device:
-            return self.loader(self.segm_paths[idx])
-        if idx not in self._segs:
+    # A pickled dataset (DataLoader worker, reference fetalsyngen/test_dl.py:17-24) carries paths and configuration only: the
+    # worker's LabelCache starts empty and re-reads the label files on first use.
+    def __getstate__(self):
+        return dict(self.__dict__)  # LabelCache / FetalSynthGen / SeedBank drop their process-local state themselves
+
+    def _subject(self, idx):
+        """(bank | None, float32 device segmentation, uint8 twin | None) of subject `idx` through the LRU."""
+        name = self._sub_ses_idx(idx)
+
+        def build():
+            bank, nbytes = None, 0
+            if self.seed_path is not None and not self.image_as_intensity:
+                vols = {n: {m: self.loader(p).numpy() for m, p in d.items()} for n, d in self.seed_paths[name].items()}
+                bank = SeedBank(vols, self.generator.device)
+                nbytes += bank.nbytes
             host = self.loader(self.segm_paths[idx]).float()
             dev = host.to(self.generator.device)
             # uint8 twin for the label gather when the segmentation is integer valued in 0..255 (always the
             # case for dseg files); results are identical, the kernel reads 1 byte instead of 4 per voxel
             ok = bool(torch.equal(host, host.round()) and host.min() >= 0 and host.max() <= 255)
-            self._segs[idx] = (dev, dev.to(torch.uint8) if ok else None)
-        return self._segs[idx][0]
+            twin = dev.to(torch.uint8) if ok else None
+            if ok:
+                self.generator.register_label_twin(dev, twin)
+            nbytes += dev.numel() * 4 + (dev.numel() if ok else 0)
+            return (bank, dev, twin), nbytes
+
+        return self._labels.get(idx, build)
+
+    def _seeds_for(self, name, idx=None):
+        if not self.cache_on_device:
+            return self.seed_paths[name]
+        if idx is None:
+            idx = [self._sub_ses_idx(k) for k in range(len(self.sub_ses))].index(name)
+        return self._subject(idx)[0]
+
+    def _segmentation(self, idx):
+        if not self.cache_on_device:
+            return self.loader(self.segm_paths[idx])
+        return self._subject(idx)[1]
 
     def _segmentation_u8(self, idx):
-        return self._segs[idx][1] if (self.cache_on_device and idx in self._segs) else None
+        if not self.cache_on_device:
+            return None
+        hit = self._labels.peek(idx)
+        return hit[2] if hit is not None else None
 
     def sample(self, idx, genparams: dict = {}):
         image = self.loader(self.img_paths[idx]).float() if self.load_image else None
         segm = self._segmentation(idx)
         name = self._sub_ses_idx(idx)
         seeds = None
-        if self.seed_path is not None:
-            seeds = self._seeds_for(name)
-        if self.image_as_intensity:
-            seeds = None
+        if self.seed_path is not None and not self.image_as_intensity:
+            seeds = self._seeds_for(name, idx)
         generation_params = {
             "idx": idx,
             "img_paths": str(self.img_paths[idx]),
@@ -223,7 +346,7 @@ class FetalSynthDataset(FetalDataset):
         indices = [int(i) for i in indices]
         names = [self._sub_ses_idx(i) for i in indices]
         t0 = time.time()
-        items = [(None, self._segmentation(i), self._seeds_for(n)) for i, n in zip(indices, names)]
+        items = [(None, self._segmentation(i), self._seeds_for(n, i)) for i, n in zip(indices, names)]
         out, seg, _imgs, params = self.generator.sample_batch(items, genparams_list, scale01=True, streams=streams,
                                                               labels_u8=self.return_device)
         if not torch.is_tensor(out):
@@ -240,6 +363,10 @@ class FetalSynthDataset(FetalDataset):
         return {"image": image, "label": label, "name": names}, gps
 
     def __getitem__(self, idx) -> dict:
+        if self.base_seed is not None:
+            from .. import sharding
+
+            sharding.seed_for_sample(self.base_seed, self.epoch * len(self) + int(idx))
         data_out, generation_params = self.sample(idx)
         self.generation_params = generation_params
         return data_out
@@ -257,7 +384,7 @@ class MemorySynthDataset(FetalSynthDataset):
     (BASELINE configs 2, 3, 5) and wherever the labels come from somewhere other than NIfTI files."""
 
     def __init__(self, generator: FetalSynthGen, segmentations, seed_volumes, return_device: bool = False,
-                 names=None):
+                 names=None, base_seed: int | None = None):
         if len(segmentations) != len(seed_volumes) or not len(segmentations):
             raise ValueError("need one seed-volume table per segmentation (and at least one subject)")
         self.bids_path, self.seed_path = Path("<memory>"), Path("<memory>")
@@ -268,9 +395,29 @@ class MemorySynthDataset(FetalSynthDataset):
         self.load_image, self.image_as_intensity = False, False
         self.generator = generator
         self.cache_on_device, self.return_device = True, return_device
-        self._banks, self._segs = {}, {}
+        self.base_seed, self.epoch = base_seed, 0
+        self._labels = None  # nothing to evict: there are no files to re-read from
+        self._mem = []       # per subject: (bank, float32 device segmentation, uint8 twin)
         dev = generator.device
-        for k, (seg, vols) in enumerate(zip(segmentations, seed_volumes)):
+        for seg, vols in zip(segmentations, seed_volumes):
             d = torch.as_tensor(np.asarray(seg) if not torch.is_tensor(seg) else seg).float().to(dev).contiguous()
-            self._segs[k] = (d, d.to(torch.uint8))
-            self._banks[self.subjects[k]] = vols if isinstance(vols, SeedBank) else SeedBank(vols, dev)
+            self._mem.append((vols if isinstance(vols, SeedBank) else SeedBank(vols, dev), d, d.to(torch.uint8)))
+            generator.register_label_twin(d, self._mem[-1][2])
+
+    # Pickling: the label volumes themselves travel (host copies; there is no file to re-read them from) and are uploaded by
+    # the worker on first use.
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_mem"] = [(bank, seg.cpu().numpy() if torch.is_tensor(seg) else seg, None) for bank, seg, _t in self._mem]
+        return state
+
+    def _subject(self, idx):
+        bank, seg, twin = self._mem[idx]
+        if not torch.is_tensor(seg):  # unpickled in another process: upload now
+            seg = torch.from_numpy(seg).to(self.generator.device).contiguous()
+            bank, seg, twin = self._mem[idx] = (bank, seg, seg.to(torch.uint8))
+            self.generator.register_label_twin(seg, twin)
+        return bank, seg, twin
+
+    def _segmentation_u8(self, idx):
+        return self._subject(idx)[2]

@@ -116,7 +116,7 @@ class PrefetchingStream:
         idx = i % len(self.ds)
         segm = self.ds._segmentation(idx)
         name = self.ds._sub_ses_idx(idx)
-        seeds = self.ds._seeds_for(name)
+        seeds = self.ds._seeds_for(name, idx)
         # device-resident hand-over: the fused warp writes the uint8 labels itself (no float32 labels, no conversion pass)
         out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True, labels_u8=self._labels_u8)
         return out, seg, name
@@ -134,7 +134,7 @@ class PrefetchingStream:
                 idx = i % len(ds)
                 name = ds._sub_ses_idx(idx)
                 names.append(name)
-                yield (None, ds._segmentation(idx), ds._seeds_for(name))
+                yield (None, ds._segmentation(idx), ds._seeds_for(name, idx))
 
         out, seg, _imgs, _params = gen.sample_batch(items(), scale01=True, streams=self.batch_streams, lazy_items=len(idxs),
                                                     labels_u8=self._labels_u8)

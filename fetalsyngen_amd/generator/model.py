@@ -106,6 +106,22 @@ class FetalSynthGen:
         self._blur_tick = 0
         self._ws = {}
 
+    # Everything below lives and dies with ONE process: raw host addresses (`_flat`: ivp / fvp / tbp are `ndarray.ctypes.data`
+    # integers), device tensors (`_ws`, `_twins`, `_arena_next`), HIP events and streams, caches keyed by `id()` of tensors of
+    # this process.  None of it is configuration, all of it is rebuilt on first use -- so a pickled generator (the reference's
+    # DataLoader pattern: `num_workers=2, multiprocessing_context="spawn"`, fetalsyngen/test_dl.py:17-24, docs/datasets.md:4-6)
+    # carries none of it into the worker.
+    _PROCESS_LOCAL = ("_ws", "_flat", "_twins", "_seen_parts", "_arena_next", "_rs_dt", "_batch_streams", "blur_events",
+                      "_blur_tick", "_keyed")
+
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in self._PROCESS_LOCAL}
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update({k: v for k, v in state.items() if k not in self._PROCESS_LOCAL})
+        self.blur_events, self._blur_tick, self._ws = None, 0, {}
+
     def prewarm(self, shape=None) -> int:
         """Build and upload every per-axis table this configuration can ask for (the low-res size of
         RandResample takes at most shape*(1 - min/max resolution) distinct values per axis; the coarse
@@ -239,21 +255,72 @@ class FetalSynthGen:
         p.out = out.data_ptr()
         return True
 
+    label_twin_budget_bytes = 1 << 30  # HBM the uint8 twins of caller-owned label volumes may take (64 at 256^3)
+
+    def _twin_cache(self):
+        return self.__dict__.setdefault("_twins", {"by_id": {}, "bytes": 0})
+
+    def _twin_drop(self, key):
+        cache = self.__dict__.get("_twins")
+        ent = cache["by_id"].pop(key, None) if cache else None
+        if ent is not None and ent[2] is not None:
+            cache["bytes"] -= ent[2].numel()
+
+    def register_label_twin(self, seg, twin):
+        """Hand over a uint8 copy of the float32 label volume `seg` (same values) that the caller already holds -- the
+        datasets do, for every subject they cache -- so that no check and no second copy is made here."""
+        if twin is None or twin.dtype != torch.uint8 or twin.shape != seg.shape or twin.device != seg.device:
+            raise ValueError("label twin must be a uint8 tensor of the segmentation's shape on its device")
+        cache = self._twin_cache()
+        key = id(seg)
+        self._twin_drop(key)
+        cache["by_id"][key] = [weakref.ref(seg, lambda _r, k=key, me=weakref.ref(self): me() and me()._twin_drop(k)),
+                               seg._version, twin, 2]
+        cache["bytes"] += twin.numel()
+
+    def invalidate_label_twins(self):
+        """Forget every cached uint8 label twin.  The cache notices a new tensor object and an in-place torch write
+        (`_version`); it cannot notice a label volume rewritten through its raw pointer (another HIP library, the `fsg_*`
+        entry points themselves) -- call this after such a write."""
+        self.__dict__.pop("_twins", None)
+        fb = self.__dict__.get("_flat")
+        if fb is not None:
+            fb["validated"].clear()
+
     def _label_twin(self, seg):
-        """uint8 copy of a float32 label volume whose values are integers in 0..255 (dseg volumes always are), cached per
-        tensor (storage address, size, in-place version): the fused warp then gathers 1 B/voxel instead of 4, the output
-        stays float32.  The one-time check synchronises; None when the volume is not integer valued."""
-        cache = self.__dict__.setdefault("_twins", {})
-        key = (seg.data_ptr(), seg.numel(), seg._version)
-        hit = cache.get(key)
-        if hit is None:
-            r = seg.round()
-            ok = bool(torch.equal(r, seg)) and float(seg.min()) >= 0 and float(seg.max()) <= 255
-            hit = (seg.to(torch.uint8) if ok else None, seg)  # the source tensor is kept so that its address stays taken
-            if len(cache) >= 64:
-                cache.pop(next(iter(cache)))
-            cache[key] = hit
-        return hit[0]
+        """uint8 copy of a float32 label volume whose values are integers in 0..255 (dseg volumes always are): the fused warp
+        then gathers 1 B/voxel instead of 4, the output stays float32.  Cached per tensor OBJECT through a weak reference
+        (the entry goes when the tensor dies, nothing keeps a caller's volume alive) together with its in-place version.
+        A volume is converted on its SECOND sighting: a caller who passes a fresh segmentation on every call never pays the
+        synchronising integer check and the extra passes, a caller who re-uses volumes pays them once.  Twins take at most
+        `label_twin_budget_bytes` (oldest dropped first).  None: no twin (yet), the warp reads the float32 volume."""
+        cache = self._twin_cache()
+        by_id = cache["by_id"]
+        key = id(seg)
+        ent = by_id.get(key)
+        if ent is not None and (ent[0]() is not seg or ent[1] != seg._version):
+            self._twin_drop(key)
+            ent = None
+        if ent is None:
+            if len(by_id) > 4096:
+                by_id.clear()
+                cache["bytes"] = 0
+            by_id[key] = [weakref.ref(seg, lambda _r, k=key, me=weakref.ref(self): me() and me()._twin_drop(k)),
+                          seg._version, None, 1]
+            return None
+        if ent[3] == 1:  # second sighting: check and convert (synchronises once per volume)
+            ent[3] = 2
+            ok = bool(torch.equal(seg.round(), seg)) and float(seg.min()) >= 0 and float(seg.max()) <= 255
+            if ok:
+                while cache["bytes"] + seg.numel() > self.label_twin_budget_bytes:
+                    victim = next((k for k, e in by_id.items() if e[2] is not None), None)
+                    if victim is None:
+                        break
+                    self._twin_drop(victim)
+                if cache["bytes"] + seg.numel() <= self.label_twin_budget_bytes:
+                    ent[2] = seg.to(torch.uint8)
+                    cache["bytes"] += seg.numel()
+        return ent[2]
 
     def _native_ok(self, c, labels_u8: bool = False) -> bool:
         """labels_u8: the caller wants uint8 labels -- the fused path then writes them itself and a caller-supplied uint8

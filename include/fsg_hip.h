@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FSG_ABI_VERSION 1
+#define FSG_ABI_VERSION 2  /* 2: fsg_sample_plan grew (mm_slots .. seg_out_u8) after version 1 shipped */
 
 #define FSG_E_BADARG (-1)   /* null pointer / non-positive size / bad enum */
 #define FSG_E_TOOBIG (-2)   /* size exceeds what the kernel indexes (2^31-1 voxels per volume) */
@@ -476,6 +476,11 @@ enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_G
 int fsg_sample_plan_pack(fsg_sample_plan* plan, const int64_t* iv, int niv, const double* fv, int nfv, const float* taps);
 int fsg_sample_pack_run(const int64_t* iv, int niv, const double* fv, int nfv, const float* taps, void* stream);
 int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams);
+
+/* Releases the library-owned side streams / events of the opt-in head overlap (fsg_sample_plan::overlap); they otherwise
+ * live for the life of the process.  Synchronise the launch streams first.  No reference counterpart (the reference owns
+ * no streams). */
+int fsg_pipeline_teardown(void);
 /* float32 -> float16 (round to nearest even) copy of a volume: the optional half-precision image of the output side. */
 int fsg_cast_f32_to_f16(const float* x, size_t n, void* out_f16, void* stream);
 

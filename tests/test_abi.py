@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_strings():
     lib = _lib.load()
-    assert lib.fsg_abi_version() == 1
+    assert lib.fsg_abi_version() == _lib.ABI_VERSION
     assert b"bad argument" in lib.fsg_error_string(-1)
     assert lib.fsg_error_string(0) == b"success"
 

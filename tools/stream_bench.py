@@ -32,7 +32,7 @@ class MiniDataset:
     def __len__(self): return 4
     def _segmentation(self, idx): return self._segs[idx]
     def _sub_ses_idx(self, idx): return f"sub-{idx}"
-    def _seeds_for(self, name): return self._banks[int(name.split("-")[1])]
+    def _seeds_for(self, name, idx=None): return self._banks[int(name.split("-")[1])]
 
 ds = MiniDataset()
 
