@@ -51,7 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--rng", default="device", choices=["device", "reference"])
+    ap.add_argument("--rng", default="keyed", choices=["keyed", "device", "reference"],
+                    help="keyed (default): every draw of a sample from Philox under its (base_seed, index) key, in C / on the "
+                         "device; device: the reference's host draw order, large fields from device Philox; reference: host tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--no-sr", action="store_true", help="skip the 384^3 SimulateMotion side line")
@@ -214,6 +216,56 @@ def blur_traffic(sections, size):
     return tot / len(launches), len(launches)
 
 
+def stage_rooflines(traces, nvox):
+    """Per-launch figures from the stage traces (HIP events behind every launch of a sample, fsg_sample_plan::trace_events):
+    mean microseconds, the algorithmic bytes of that launch (SURVEY 8(d) per-unit figures x the voxels it processes: N =
+    full grid, M = low-res grid of THAT sample) and the fraction of the HBM peak.  Each interval holds one barrier packet
+    besides the kernel, so `us` is an upper bound of the kernel's own duration (rocprof's per-kernel averages are in
+    profiles/)."""
+    import numpy as np
+
+    def alg_bytes(stage, meta):
+        N = float(np.prod(meta["shape"]))
+        M = float(np.prod(meta["low_shape"])) if meta.get("low_shape") else N
+        m0 = meta["low_shape"][0] if meta.get("low_shape") else meta["shape"][0]
+        return {
+            "upload": 65536.0, "draw": 65536.0,
+            "head": 8.0 * N,               # 4 x uint8 seed volumes read + float32 image written (K1; rows / face minima ~0)
+            "gmm": 8.0 * N,
+            "floormin": 0.0,               # reads the coarse grid only
+            "rows": 0.0,
+            "warp": 13.0 * N,              # image 4 + 4, uint8 label twin 1, float32 labels 4 (K4a + K4b, K5 fused: 0)
+            "blur_x": 8.0 * N, "blur_y": 8.0 * N, "blur_z": 8.0 * N,
+            "blur_yz": 8.0 * N,            # two axis passes for one read + one write of the volume
+            "k7": 4.0 * N + 4.0 * M,
+            "k9a": 4.0 * M,                # min / max of the zoom-back: reads the low-res volume, writes nothing
+            "k9b": 4.0 * M + 4.0 * N,
+            "blur_rs_x": 4.0 * N + 4.0 * N * m0 / meta["shape"][0],
+            "blur_rs_yz": 4.0 * N * m0 / meta["shape"][0] + 4.0 * M,
+            "pointwise": 8.0 * N,
+        }.get(stage, 0.0)
+
+    acc = {}
+    for tr in traces:
+        for stage, us in tr.elapsed_us():
+            a = acc.setdefault(stage, {"us": [], "bytes": []})
+            a["us"].append(us)
+            a["bytes"].append(alg_bytes(stage, tr.meta or {"shape": (1, 1, 1)}))
+    out, total = {}, 0.0
+    for stage, a in acc.items():
+        us, by = float(np.mean(a["us"])), float(np.mean(a["bytes"]))
+        total += us * len(a["us"]) / max(len(traces), 1)
+        out[stage] = {"us": round(us, 2), "us_min": round(float(np.min(a["us"])), 2), "us_max": round(float(np.max(a["us"])), 2),
+                      "launches_per_sample": round(len(a["us"]) / max(len(traces), 1), 2),
+                      "algorithmic_bytes": int(by), "GBps": round(by / us / 1e3, 1) if us > 0 else None,
+                      "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 4) if us > 0 else None}
+    out["_sum_us_per_sample"] = round(total, 2)
+    out["_samples"] = len(traces)
+    out["_note"] = ("untimed pass after the timed region, one event behind every launch: each interval = the launch + one "
+                    "barrier packet, so the sum exceeds ms_per_step of the un-instrumented run")
+    return out
+
+
 def blur_microbench(shape, device, sigma=1.3, reps=20):
     """Back-to-back launches of each blur kernel between HIP events.  GBps = bytes the launch must move (read the volume
     once + write it once = 8 B/voxel, also for the fused y+z launch, whose intermediate never leaves LDS) / time; the
@@ -354,17 +406,27 @@ def run_dry_plan(args, R: Ranks):
     from fetalsyngen_amd import sharding
 
     shape = (args.size,) * 3
-    gen = build_generator(shape, "cuda:0", args.rng if args.rng == "device" else "device")
-    for i in range(args.warmup):
-        sharding.seed_for_sample(1234, R.rank + R.world * i)
-        gen.plan_only(shape)
-    R.barrier()
-    t0 = time.perf_counter()
+    gen = build_generator(shape, "cuda:0", args.rng if args.rng != "reference" else "device")
     digest = 0.0
-    for i in range(args.steps):
-        sharding.seed_for_sample(1234, R.rank + R.world * (args.warmup + i))
-        plans = gen.plan_only(shape)
-        digest += float(plans[1].mus.sum())
+    if args.rng == "keyed":  # the host side of a keyed sample: the key and the C draws (fsg_keyed_draw, no GPU)
+        kc = gen.keyed_context(shape)
+        for i in range(args.warmup):
+            kc.draws(sharding.sample_key(1234, R.rank + R.world * i))
+        R.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            d = kc.draws(sharding.sample_key(1234, R.rank + R.world * (args.warmup + i)))
+            digest += d.spacing + d.gamma
+    else:
+        for i in range(args.warmup):
+            sharding.seed_for_sample(1234, R.rank + R.world * i)
+            gen.plan_only(shape)
+        R.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sharding.seed_for_sample(1234, R.rank + R.world * (args.warmup + i))
+            plans = gen.plan_only(shape)
+            digest += float(plans[1].mus.sum())
     R.barrier()
     dt_rank = time.perf_counter() - t0
     dt = R.max(dt_rank)
@@ -375,7 +437,7 @@ def run_dry_plan(args, R: Ranks):
             "metric": "host plans/sec (dry plan: all per-sample host draws, no GPU work)", "value": round(R.world * args.steps / dt, 1),
             "unit": "plans/s", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64/f32 host", "data": "synthetic", "dry_plan": True,
+            "dtype": "f64/f32 host", "data": "synthetic", "dry_plan": True, "rng": args.rng,
             "config": {"workload": f"host plans of BASELINE configs[1] ({args.size}^3), no device work"},
             "ranks_seen": sorted(r["rank"] for r in reports), "ranks": reports}), flush=True)
 
@@ -441,15 +503,21 @@ def run(args, rank, world, local):
     streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else [None]
     mus_seen = []
 
+    keyed = args.rng == "keyed"
+
     def step(i):
-        sharding.seed_for_sample(1234, rank + world * i)
+        if keyed:
+            key = sharding.sample_key(1234, rank + world * i)
+        else:
+            key = None
+            sharding.seed_for_sample(1234, rank + world * i)
         k = i % 4
         st = streams[i % len(streams)]
         if st is None:
-            out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True)
+            out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True, key=key)
         else:
             with torch.cuda.stream(st):
-                out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True)
+                out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True, key=key)
         return out, seg_d, p
 
     # ---- headline: BASELINE configs[1], W untimed + K timed steps, barrier + synchronize on both sides ----------
@@ -484,6 +552,18 @@ def run(args, rank, world, local):
     R.barrier()
     dt_rank = time.perf_counter() - t0
     dt = R.max(dt_rank)
+
+    # ---- per-launch times of the same samples' kind, UNTIMED: HIP events behind every launch of 16 further samples ------------
+    gen.blur_events_save, gen.blur_events = gen.blur_events, None
+    gen.stage_traces = []
+    for i in range(16):
+        step(20_000_000 + i)
+    torch.cuda.synchronize()
+    traces, gen.stage_traces = gen.stage_traces, None
+    gen.blur_events = gen.blur_events_save
+    roofline_kernels = stage_rooflines(traces, nvox)
+    for tr in traces:
+        tr.close()
 
     lib = _lib.load()
     blur_total_ms, sections = 0.0, []
@@ -543,6 +623,7 @@ def run(args, rank, world, local):
                           "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    result["roofline_kernels"] = roofline_kernels
     result.update(result_extra)
 
     # ---- config3: a batch of B volumes dealt i % N (strong scaling), per-sample keys independent of N -------------
@@ -558,8 +639,12 @@ def run(args, rank, world, local):
             R.barrier()
             t0 = time.perf_counter()
             for i in mine:
-                sharding.seed_for_sample(4321, i)
-                o, s_, _im, _p = gen._pipeline(None, subj[i][0], subj[i][1], {}, scale01=True)
+                if keyed:
+                    ckey = sharding.sample_key(4321, i)
+                else:
+                    ckey = None
+                    sharding.seed_for_sample(4321, i)
+                o, s_, _im, _p = gen._pipeline(None, subj[i][0], subj[i][1], {}, scale01=True, key=ckey)
                 outs[i] = (o, s_)
             torch.cuda.synchronize()
             R.barrier()

@@ -100,7 +100,54 @@ class SamplePlan(C.Structure):
         ("overlap", C.c_int32),
         ("ws_seq", C.c_uint64),
         ("seg_out_u8", C.c_void_p),
+        ("trace_events", C.c_void_p),
+        ("trace_ids", C.c_void_p),
+        ("trace_cap", C.c_int32),
     ]
+
+
+class KeyedConfig(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int32 * 3), ("size", C.c_int32 * 3), ("resolution", C.c_double * 3),
+        ("min_subclusters", C.c_int32), ("max_subclusters", C.c_int32), ("meta_labels", C.c_int32),
+        ("nlabels", C.c_int32), ("n_seed_labels", C.c_int32), ("tie_classes", C.c_int32),
+        ("seed_labels", C.c_uint8 * 256), ("generation_classes", C.c_uint8 * 256),
+        ("deform_prob", C.c_double), ("flip_prb", C.c_double), ("max_rotation", C.c_double), ("max_shear", C.c_double),
+        ("max_scaling", C.c_double), ("nonlinear", C.c_int32),
+        ("nonlin_scale_min", C.c_double), ("nonlin_scale_max", C.c_double), ("nonlin_std_max", C.c_double),
+        ("gamma_prob", C.c_double), ("gamma_std", C.c_double),
+        ("bias_prob", C.c_double), ("bf_scale_min", C.c_double), ("bf_scale_max", C.c_double), ("bf_std_min", C.c_double),
+        ("bf_std_max", C.c_double),
+        ("resample_prob", C.c_double), ("min_resolution", C.c_double), ("max_resolution", C.c_double),
+        ("noise_prob", C.c_double), ("noise_std_min", C.c_double), ("noise_std_max", C.c_double),
+    ]
+
+
+class KeyedDraws(C.Structure):
+    _fields_ = [
+        ("key", C.c_uint64), ("subclusters", C.c_int32 * 4), ("ntab", C.c_int32),
+        ("deform_active", C.c_int32), ("flip", C.c_int32),
+        ("rotations", C.c_double * 3), ("shears", C.c_double * 3), ("scalings", C.c_double * 3),
+        ("A", C.c_float * 9), ("c2", C.c_double * 3),
+        ("nonlinear", C.c_int32), ("nonlin_scale", C.c_double), ("nonlin_std", C.c_double), ("field_dims", C.c_int32 * 3),
+        ("gamma_active", C.c_int32), ("gamma", C.c_double),
+        ("bias_active", C.c_int32), ("bf_scale", C.c_double), ("bf_std", C.c_double), ("bias_dims", C.c_int32 * 3),
+        ("resample_active", C.c_int32), ("spacing", C.c_double), ("u_std", C.c_double), ("stds", C.c_double * 3),
+        ("low_shape", C.c_int32 * 3), ("blur_ntaps", C.c_int32 * 3),
+        ("noise_active", C.c_int32), ("noise_std", C.c_double), ("noise_std32", C.c_float),
+        ("off_mm8", C.c_int32), ("off_slots", C.c_int32), ("off_mus", C.c_int32), ("off_sigmas", C.c_int32),
+        ("off_bias", C.c_int32), ("off_field", C.c_int32), ("block_bytes", C.c_int32),
+    ]
+
+
+E_NOTABLE = -4
+KT_RESAMPLE, KT_BACK, KT_FIELD, KT_BIAS = 0, 1, 2, 3
+KEYED_I = dict(KEY=0, OUT=1, SEG_OUT=2, SEG_OUT_U8=3, SEG_IN=4, SEG_IN_U8=5, BLOCK=6, WS0=7, WS1=8, WS_LOW=9, WS_ROWS=10,
+               ROW_STRIDE=11, SCALE01=12, TRACE_EVENTS=13, TRACE_IDS=14, TRACE_CAP=15, BANK=16, EV_BLUR_BEGIN=80,
+               EV_BLUR_END=81, COUNT=82)
+
+STAGE_NAMES = ("begin", "upload", "draw", "head", "floormin", "warp", "blur_x", "blur_y", "blur_z", "blur_yz", "k7", "k9a", "k9b",
+               "gmm", "rows", "pointwise", "blur_rs_x", "blur_rs_yz")  # include/fsg_hip.h: FSG_ST_*
 
 
 P, I, F, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -170,11 +217,18 @@ SIGNATURES = {
     "fsg_sample_run_batch": [C.POINTER(SamplePlan), I, C.POINTER(C.c_void_p), I],
     "fsg_cast_f32_to_f16": [P, SZ, P, P],
     "fsg_pipeline_teardown": [],
+    "fsg_keyed_create": [C.POINTER(KeyedConfig), C.POINTER(C.c_void_p)],
+    "fsg_keyed_destroy": [P],
+    "fsg_keyed_set_table": [P, I, I, I, P],
+    "fsg_keyed_draw": [P, U64, C.POINTER(KeyedDraws)],
+    "fsg_keyed_sample_run": [P, P, I, P, P],
+    "fsg_keyed_fill_block": [P, C.POINTER(KeyedDraws), P, P],
     "fsg_event_destroy": [P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
 }
 SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32]),
-                   "fsg_event_create": (C.c_void_p, []), "fsg_sample_plan_layout": (C.c_int64, [I])}
+                   "fsg_event_create": (C.c_void_p, []), "fsg_sample_plan_layout": (C.c_int64, [I]),
+                   "fsg_keyed_block_bytes": (C.c_int64, [P])}
 
 _lib = None
 

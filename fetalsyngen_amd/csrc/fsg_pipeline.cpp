@@ -92,6 +92,18 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   if (n > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
 
+  // stage trace (measurement only): an event behind every launch, see fsg_sample_plan::trace_events
+  int ntrace = 0;
+  auto mark = [&](int id) -> int {
+    if (!p->trace_events || !p->trace_ids || ntrace >= p->trace_cap) return 0;
+    hipError_t e = hipEventRecord((hipEvent_t)p->trace_events[ntrace], st);
+    if (e != hipSuccess) return (int)e;
+    p->trace_ids[ntrace++] = id;
+    p->trace_ids[p->trace_cap] = ntrace;
+    return 0;
+  };
+  FSG_TRY(mark(FSG_ST_BEGIN));
+
   const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
   bool head_done = false;
   fsg_deform dh = p->deform;
@@ -127,6 +139,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   if (p->arena_host) {
     if (!p->arena_dev || (p->arena_bytes & 15)) return FSG_E_BADARG;
     FSG_TRY(fsg_copy_bytes(p->arena_dev, p->arena_host, (size_t)p->arena_bytes, hstream));
+    if (!ho) FSG_TRY(mark(FSG_ST_UPLOAD));
   }
   int head_rc = 0;
   if (fused_head) {
@@ -137,6 +150,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
                                   p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
                                   p->ws_rows, p->row_stride, p->mm8, hstream);
     if (head_rc == 0) head_done = true;
+    if (head_done && !ho) FSG_TRY(mark(FSG_ST_HEAD));
   }
   if (ho) {  // whatever happened on the side stream is ordered before the rest of the sample (and before any fallback)
     FSG_HIP(hipEventRecord(ho->ev_head, ho->side));
@@ -149,6 +163,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     FSG_TRY(fsg_gmm_sample_u8x4_mm(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n,
                                    p->mus, p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0,
                                    p->mm8_preset ? nullptr : p->mm8, 4, 4, stream));
+  if (!head_done) FSG_TRY(mark(FSG_ST_GMM));
   float* cur = p->ws0;
   float* other = p->ws1;
 
@@ -161,11 +176,13 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       d.rows = p->ws_rows;
       d.row_stride = p->row_stride;
       FSG_TRY(fsg_coords_floormin_rest_f32(&d, p->mm8, stream));
+      FSG_TRY(mark(FSG_ST_FLOORMIN));
     } else {
       if (p->ws_rows && need > 0 && need <= p->row_stride) {
         d.rows = nullptr;
         d.row_stride = 0;
         FSG_TRY(fsg_deform_rows_f32(&d, &p->epi, p->ws_rows, p->row_stride, stream));
+        FSG_TRY(mark(FSG_ST_ROWS));
         d.rows = p->ws_rows;
         d.row_stride = p->row_stride;
       } else {
@@ -177,6 +194,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
         return FSG_E_TOOBIG;     // the Python orchestration handles this rare configuration stage by stage
       }
       FSG_TRY(rc);
+      FSG_TRY(mark(FSG_ST_FLOORMIN));
     }
     int rw = FSG_E_ALIGN;
     if (p->seg_out_u8) {  // uint8 labels in and out (same values: labels are integers 0..255)
@@ -187,15 +205,18 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       if (rw == FSG_E_ALIGN) rw = fsg_warp_f32(&d, p->mm8, cur, other, p->seg_in, p->seg_out, &p->epi, stream);
     }
     FSG_TRY(rw);
+    FSG_TRY(mark(FSG_ST_WARP));
     float* t = cur; cur = other; other = t;
   } else {
     if (has_gamma) {
       FSG_TRY(fsg_gamma_f32(cur, n, p->epi.gamma, other, stream));
+      FSG_TRY(mark(FSG_ST_POINTWISE));
       float* t = cur; cur = other; other = t;
     }
     if (has_bias) {
       FSG_TRY(fsg_bias_mul_f32(cur, n0, n1, n2, p->epi.bias, p->epi.bias_dims[0], p->epi.bias_dims[1],
                                p->epi.bias_dims[2], p->epi.bx, p->epi.by, p->epi.bz, other, stream));
+      FSG_TRY(mark(FSG_ST_POINTWISE));
       float* t = cur; cur = other; other = t;
     }
   }
@@ -212,6 +233,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
         int rf = fsg_blur_yz_taps_host_f32(cur, other, n0, n1, n2, p->blur_taps[1], nt, p->blur_taps[2], p->blur_ntaps[2],
                                            stream);
         if (rf == 0) {
+          FSG_TRY(mark(FSG_ST_BLUR_YZ));
           float* t = cur; cur = other; other = t;
           break;
         }
@@ -220,6 +242,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       int rc = fsg_blur_axis_taps_host_f32(cur, other, n0, n1, n2, axis, p->blur_taps[axis], nt, stream);
       if (rc == FSG_E_ALIGN) return FSG_E_ALIGN;  // shape outside the tuned kernels: stage-by-stage path
       FSG_TRY(rc);
+      FSG_TRY(mark(FSG_ST_BLUR_X + axis));
       float* t = cur; cur = other; other = t;
     }
     if (p->ev_blur_end && hipEventRecord((hipEvent_t)p->ev_blur_end, st) != hipSuccess) return FSG_E_BADARG;
@@ -238,18 +261,23 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     if (!k7_reads_ws0) FSG_TRY(mark_free());
     FSG_TRY(fsg_resample_noise_f32(cur, n0, n1, n2, p->rs_tab[0], p->rs_tab[1], p->rs_tab[2], p->ws_low, m0, m1, m2,
                                    p->noise_mode, p->noise, p->noise_seed, p->noise_stream, p->noise_std, stream));
+    FSG_TRY(mark(FSG_ST_K7));
     if (k7_reads_ws0) FSG_TRY(mark_free());
     if (p->mm_slots && p->mm_nslots >= 2 && p->mm_nslots <= 64) {  // keys sharded over slots: no contended address
       FSG_TRY(fsg_zoom3d_minmax_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1,
                                             n2, p->mm_slots, p->mm_nslots, stream));
+      FSG_TRY(mark(FSG_ST_K9A));
       FSG_TRY(fsg_zoom3d_normalise_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out,
                                                n0, n1, n2, p->mm_slots, p->mm_nslots, p->scale01 ? 1 : 0, stream));
+      FSG_TRY(mark(FSG_ST_K9B));
       return 0;
     }
     FSG_TRY(fsg_zoom3d_minmax_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1, n2,
                                   p->mm8 + 3, stream));
+    FSG_TRY(mark(FSG_ST_K9A));
     FSG_TRY(fsg_zoom3d_normalise_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out, n0,
                                      n1, n2, p->mm8 + 3, p->scale01 ? 1 : 0, stream));
+    FSG_TRY(mark(FSG_ST_K9B));
     return 0;
   }
 
@@ -354,6 +382,9 @@ extern "C" int fsg_sample_plan_pack(fsg_sample_plan* p, const int64_t* iv, int n
   q.overlap = (int32_t)iv[FSG_PLAN_I_OVERLAP];
   q.ws_seq = (uint64_t)iv[FSG_PLAN_I_WS_SEQ];
   q.seg_out_u8 = (uint8_t*)(uintptr_t)iv[FSG_PLAN_I_SEG_OUT_U8];
+  q.trace_events = (void**)(uintptr_t)iv[FSG_PLAN_I_TRACE_EVENTS];
+  q.trace_ids = (int32_t*)(uintptr_t)iv[FSG_PLAN_I_TRACE_IDS];
+  q.trace_cap = (int32_t)iv[FSG_PLAN_I_TRACE_CAP];
   *p = q;
   return 0;
 }

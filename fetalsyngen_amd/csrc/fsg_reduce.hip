@@ -127,6 +127,7 @@ const char* fsg_error_string(int code) {
   if (code == FSG_E_BADARG) return "fsg: bad argument (null pointer, non-positive size or bad enum)";
   if (code == FSG_E_TOOBIG) return "fsg: size exceeds kernel index range";
   if (code == FSG_E_ALIGN) return "fsg: shape/alignment not supported by the fast path";
+  if (code == FSG_E_NOTABLE) return "fsg: keyed mode needs a tap table that was not registered (fsg_keyed_set_table)";
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "fsg: unknown error";
 }

@@ -366,7 +366,10 @@ class FetalSynthDataset(FetalDataset):
         if self.base_seed is not None:
             from .. import sharding
 
-            sharding.seed_for_sample(self.base_seed, self.epoch * len(self) + int(idx))
+            if self.generator._is_keyed():
+                sharding.announce_key(self.base_seed, self.epoch * len(self) + int(idx))
+            else:
+                sharding.seed_for_sample(self.base_seed, self.epoch * len(self) + int(idx))
         data_out, generation_params = self.sample(idx)
         self.generation_params = generation_params
         return data_out

@@ -112,7 +112,11 @@ class PrefetchingStream:
         return len(self.indices)
 
     def _produce(self, i):
-        sharding.seed_for_sample(self.base_seed, i)
+        # keyed mode: the sample is a function of its key alone -- no re-seeding of the global generators
+        if self.ds.generator._is_keyed():
+            sharding.announce_key(self.base_seed, i)
+        else:
+            sharding.seed_for_sample(self.base_seed, i)
         idx = i % len(self.ds)
         segm = self.ds._segmentation(idx)
         name = self.ds._sub_ses_idx(idx)
@@ -127,6 +131,16 @@ class PrefetchingStream:
         by `_prepare` right after its seeding, through the items iterator."""
         ds, gen = self.ds, self.ds.generator
         names = []
+        if gen._is_keyed():
+            items = []
+            for i in idxs:
+                idx = i % len(ds)
+                name = ds._sub_ses_idx(idx)
+                names.append(name)
+                items.append((None, ds._segmentation(idx), ds._seeds_for(name, idx)))
+            out, seg, _imgs, _params = gen.sample_batch(items, scale01=True, streams=self.batch_streams, labels_u8=self._labels_u8,
+                                                        keys=[sharding.sample_key(self.base_seed, i) for i in idxs])
+            return out, seg, names
 
         def items():
             for i in idxs:

@@ -61,6 +61,44 @@ class _Ctx:
     """One prepared sample: its plans, arena offsets and (after _resolve) device views."""
 
 
+class StageTrace:
+    """HIP events behind every launch of ONE sample (fsg_sample_plan::trace_events): per-launch times on the launch stream,
+    measured where the launches happen.  Measurement only: each record is a barrier packet (~5 us of bubble)."""
+
+    CAP = 16
+
+    def __init__(self):
+        import ctypes as C
+
+        lib = _lib.load()
+        self.events = (C.c_void_p * self.CAP)(*[lib.fsg_event_create() for _ in range(self.CAP)])
+        self.ids = np.zeros(self.CAP + 1, dtype=np.int32)
+        self.meta = None
+
+    def slots(self):
+        import ctypes as C
+
+        return C.addressof(self.events), self.ids.ctypes.data, self.CAP
+
+    def elapsed_us(self):
+        """[(stage name, microseconds between the previous event and this launch's event)]; synchronises."""
+        import ctypes as C
+
+        lib, ms, out = _lib.load(), C.c_float(), []
+        n = int(self.ids[self.CAP])
+        for k in range(1, n):
+            _lib.check(lib.fsg_event_elapsed_ms(self.events[k - 1], self.events[k], C.byref(ms)), "fsg_event_elapsed_ms")
+            out.append((_lib.STAGE_NAMES[int(self.ids[k])], ms.value * 1e3))
+        return out
+
+    def close(self):
+        lib = _lib.load()
+        for e in self.events:
+            if e:
+                lib.fsg_event_destroy(e)
+        self.events = ()
+
+
 class FetalSynthGen:
     def __init__(
         self,
@@ -104,6 +142,7 @@ class FetalSynthGen:
         self.blur_events = None      # set to a list to have HIP events recorded around each sample's blur passes
         self.blur_events_every = 1   # ... of every k-th sample only (an event record is a barrier packet: ~5.5 us of bubble)
         self._blur_tick = 0
+        self.stage_traces = None     # set to a list: every fused sample appends a StageTrace (per-launch HIP events)
         self._ws = {}
 
     # Everything below lives and dies with ONE process: raw host addresses (`_flat`: ivp / fvp / tbp are `ndarray.ctypes.data`
@@ -112,7 +151,7 @@ class FetalSynthGen:
     # DataLoader pattern: `num_workers=2, multiprocessing_context="spawn"`, fetalsyngen/test_dl.py:17-24, docs/datasets.md:4-6)
     # carries none of it into the worker.
     _PROCESS_LOCAL = ("_ws", "_flat", "_twins", "_seen_parts", "_arena_next", "_rs_dt", "_batch_streams", "blur_events",
-                      "_blur_tick", "_keyed")
+                      "_blur_tick", "_keyed", "stage_traces")
 
     def __getstate__(self):
         state = {k: v for k, v in self.__dict__.items() if k not in self._PROCESS_LOCAL}
@@ -120,7 +159,7 @@ class FetalSynthGen:
 
     def __setstate__(self, state):
         self.__dict__.update({k: v for k, v in state.items() if k not in self._PROCESS_LOCAL})
-        self.blur_events, self._blur_tick, self._ws = None, 0, {}
+        self.blur_events, self._blur_tick, self._ws, self.stage_traces = None, 0, {}, None
 
     def prewarm(self, shape=None) -> int:
         """Build and upload every per-axis table this configuration can ask for (the low-res size of
@@ -367,7 +406,7 @@ class FetalSynthGen:
               BIAS_TABS=29, RESAMPLE_ACTIVE=32, LOW_SHAPE=33, RS_TABS=36, BACK_TABS=39, BLUR_NTAPS=42, NOISE_MODE=45, NOISE=46,
               NOISE_SEED=47, NOISE_STREAM=48, SCALE01=49, WS0=50, WS1=51, WS_LOW=52, WS_ROWS=53, ROW_STRIDE=54, MM8=55,
               MM8_PRESET=56, OUT=57, EV_BEGIN=58, EV_END=59, MM_SLOTS=60, MM_NSLOTS=61, ARENA_HOST=62, ARENA_DEV=63,
-              ARENA_BYTES=64, OVERLAP=65, WS_SEQ=66, SEG_OUT_U8=67, COUNT=68)
+              ARENA_BYTES=64, OVERLAP=65, WS_SEQ=66, SEG_OUT_U8=67, TRACE_EVENTS=68, TRACE_IDS=69, TRACE_CAP=70, COUNT=71)
     _TAPS_STRIDE = 132
 
     def _flat_buffers(self):
@@ -462,6 +501,12 @@ class FetalSynthGen:
         iv[I["OUT"]] = out.data_ptr()
         if events is not None:
             iv[I["EV_BEGIN"]], iv[I["EV_END"]] = events
+        if self.stage_traces is not None:
+            tr = StageTrace()
+            tr.meta = {"shape": tuple(shape), "low_shape": tuple(rplan.new_size) if rplan.active else None,
+                       "blur_ntaps": [int(iv[I["BLUR_NTAPS"] + a_]) for a_ in range(3)]}
+            iv[I["TRACE_EVENTS"]], iv[I["TRACE_IDS"]], iv[I["TRACE_CAP"]] = tr.slots()
+            self.stage_traces.append(tr)
         if arena.pending is not None:  # staged, not yet copied: the call uploads (Arena.stage)
             iv[I["ARENA_HOST"]], iv[I["ARENA_DEV"]], iv[I["ARENA_BYTES"]] = arena.pending[2], base, arena.pending[3]
             iv[I["OVERLAP"]], iv[I["WS_SEQ"]] = int(self._overlap_ok(c)), ws["seq"]
@@ -672,8 +717,9 @@ class FetalSynthGen:
         }
 
     # ---- fused path -----------------------------------------------------------------------------
-    def sample(self, image, segmentation, seeds, genparams: dict = {}):
-        out, seg, img, params = self._pipeline(image, segmentation, seeds, genparams, scale01=False)
+    def sample(self, image, segmentation, seeds, genparams: dict = {}, key: int | None = None):
+        """`key`: keyed mode only (`rng="keyed"`), the sample's 64-bit key."""
+        out, seg, img, params = self._pipeline(image, segmentation, seeds, genparams, scale01=False, key=key)
         return out, seg, img, params
 
     def _draw_plans(self, shape, genparams):
@@ -883,9 +929,116 @@ class FetalSynthGen:
     def _synth_params(self, c, artifacts):
         return self._params(c.selected_seeds, c.seed_intensities, c.dplan, c.g, c.bplan, c.rplan, c.nplan, artifacts)
 
-    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None, labels_u8: bool = False):
+    # ---- keyed mode (fetalsyngen_amd/keyed.py, csrc/fsg_keyed.hip) -----------------------------------------------------
+    def keyed_context(self, shape):
+        from .. import keyed
+
+        ctxs = self.__dict__.setdefault("_keyed", {})
+        shape = tuple(int(v) for v in shape)
+        kc = ctxs.get(shape)
+        if kc is None:
+            if len(ctxs) >= 4:
+                ctxs.pop(next(iter(ctxs))).close()
+            kc = ctxs[shape] = keyed.KeyedContext(self, shape)
+        return kc
+
+    def _is_keyed(self) -> bool:
+        return (self.rng or _rng.get_mode()) == "keyed"
+
+    def _keyed_applies(self, image, segmentation, seeds, genparams, segmentation_u8, labels_u8) -> bool:
+        return (self.native_pipeline and image is None and not genparams and hasattr(seeds, "parts")
+                and self.intensity_generator.meta_labels <= 4 and torch.is_tensor(segmentation) and segmentation.is_cuda
+                and segmentation.dtype == torch.float32 and segmentation.is_contiguous()
+                and (segmentation_u8 is None or labels_u8) and not any(a is not None for a in self.artifacts.values()))
+
+    def _pipeline_keyed(self, segmentation, bank, key, scale01, labels_u8, out=None, seg_out=None):
+        """One keyed sample: pointers + key -> ONE native call (draws, the draw kernel, the launch sequence).  Returns
+        (image, labels, None, synth_params) or None when the sample is outside the fused kernels' domain."""
+        from .. import keyed
+
+        shape = tuple(segmentation.shape)
+        kc = self.keyed_context(shape)
+        if not kc._tables_ready:
+            kc.register_tables()
+        twin = self._label_twin(segmentation)
+        if labels_u8 and twin is None:
+            return None
+        ent = kc.subject(bank, segmentation, twin)
+        dev = segmentation.device
+        ws = self._workspace(shape, kc.rows_need)
+        given = seg_out is not None
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+        if seg_out is None:
+            seg_out = torch.empty(shape, dtype=torch.uint8 if labels_u8 else torch.float32, device=dev)
+        block = torch.empty(kc.block_bytes, dtype=torch.uint8, device=dev)
+        iv = kc.iv
+        iv[0] = key if key < (1 << 63) else key - (1 << 64)
+        iv[1] = out.data_ptr()
+        if labels_u8:
+            iv[2], iv[3] = 0, seg_out.data_ptr()
+        else:
+            iv[2], iv[3] = seg_out.data_ptr(), 0
+        iv[4], iv[5], iv[6] = ent[2], ent[1], block.data_ptr()
+        iv[7], iv[8], iv[9] = ws["ws0"].data_ptr(), ws["ws1"].data_ptr(), ws["low"].data_ptr()
+        iv[10], iv[11], iv[12] = (ws["rows"].data_ptr() if ws["rows"] is not None else 0), ws["stride"], int(bool(scale01))
+        tr = None
+        if self.stage_traces is not None:
+            tr = StageTrace()
+            iv[13], iv[14], iv[15] = tr.slots()
+        else:
+            iv[13] = iv[14] = iv[15] = 0
+        iv[16:80] = ent[0]
+        events = None
+        if self.blur_events is not None:
+            self._blur_tick += 1
+            if self._blur_tick % self.blur_events_every == 0:
+                events = (kc.lib.fsg_event_create(), kc.lib.fsg_event_create())
+        iv[80], iv[81] = events if events is not None else (0, 0)
+        d = _lib.KeyedDraws()
+        import ctypes as C
+
+        rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, 82, C.byref(d), K._stream(dev))
+        if events is not None:
+            if rc == 0 and d.resample_active:
+                self.blur_events.append((events[0], events[1], [(a_, int(d.blur_ntaps[a_]) // 2) for a_ in range(3) if d.blur_ntaps[a_]]))
+            else:
+                kc.lib.fsg_event_destroy(events[0])
+                kc.lib.fsg_event_destroy(events[1])
+        if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
+            return None
+        _lib.check(rc, "fsg_keyed_sample_run")
+        if tr is not None:
+            tr.meta = {"shape": shape, "low_shape": tuple(d.low_shape) if d.resample_active else None,
+                       "blur_ntaps": list(d.blur_ntaps)}
+            self.stage_traces.append(tr)
+        if not d.deform_active:  # no warp ran: the labels pass through
+            if given:
+                seg_out.copy_(twin if labels_u8 else segmentation)
+            else:
+                seg_out = twin if labels_u8 else segmentation
+        return out, seg_out, None, keyed.params_of(d, block)
+
+    def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None, labels_u8: bool = False,
+                  key: int | None = None):
         """labels_u8: return the labels as uint8 (same values; written as such by the fused warp where the fused path runs,
-        converted afterwards otherwise)."""
+        converted afterwards otherwise).  key (keyed mode): the sample's 64-bit key; None = the key announced by
+        `sharding.seed_for_sample` / `announce_key`, else one drawn from numpy's global generator."""
+        if self._is_keyed():
+            from .. import sharding
+
+            if key is None:
+                key = sharding.take_key()
+            if key is None:
+                key = int(np.random.randint(0, 1 << 62)) << 1
+            key &= 0xFFFFFFFFFFFFFFFF
+            if self._keyed_applies(image, segmentation, seeds, genparams, segmentation_u8, labels_u8):
+                got = self._pipeline_keyed(segmentation, seeds, key, scale01, labels_u8)
+                if got is not None:
+                    return got
+            # outside the keyed path's domain: a "device"-mode sample of the global generators seeded from the key
+            np.random.seed(key & 0xFFFFFFFF)
+            torch.default_generator.manual_seed(key >> 1)
         if labels_u8:
             out, seg, img, params = self._pipeline_f(image, segmentation, seeds, genparams, scale01, segmentation_u8, True)
             return out, (seg if seg.dtype == torch.uint8 else seg.to(torch.uint8)), img, params
@@ -931,7 +1084,7 @@ class FetalSynthGen:
             return self._run_stagewise(c, scale01)
 
     def sample_batch(self, items, genparams_list=None, scale01: bool = False, streams: int = 1, lazy_items: int | None = None,
-                     labels_u8: bool = False):
+                     labels_u8: bool = False, keys=None):
         """B samples with one parameter upload and one native call.
 
         items: sequence of (image | None, segmentation, seeds) as for `sample`; the host draws are made sample by sample
@@ -952,6 +1105,12 @@ class FetalSynthGen:
             B = len(items)
         else:
             B = int(lazy_items)
+        if keys is not None and self._is_keyed() and genparams_list is None:
+            got = self._sample_batch_keyed(list(items), [int(k) for k in keys], scale01, streams, labels_u8)
+            if got is not None:
+                return got
+            raise ValueError("keyed sample_batch: items outside the fused keyed path (need device-resident SeedBank subjects "
+                             "of one shape, no image, no SR-artifact stages)")
         genparams_list = list(genparams_list) if genparams_list is not None else [{}] * B
         if len(genparams_list) != B:
             raise ValueError("genparams_list must have one entry per item")
@@ -1016,6 +1175,43 @@ class FetalSynthGen:
         ldt = torch.uint8 if labels_u8 else torch.float32
         labels = torch.stack([o[1].to(ldt) for o in outs]) if same else [o[1].to(ldt) if labels_u8 else o[1] for o in outs]
         return images, labels, [o[2] for o in outs], [o[3] for o in outs]
+
+    def _sample_batch_keyed(self, items, keys, scale01, streams, labels_u8):
+        """B keyed samples written straight into one (B,H,W,D) tensor per output; sample b is `sample(..., key=keys[b])`."""
+        B = len(items)
+        if B == 0 or len(keys) != B:
+            return None
+        if not all(self._keyed_applies(img, seg, seeds, {}, None, labels_u8) for img, seg, seeds in items):
+            return None
+        shapes = {tuple(seg.shape) for _i, seg, _s in items}
+        if len(shapes) != 1:
+            return None
+        shape = shapes.pop()
+        dev = torch.device(self.device)
+        out_all = torch.empty((B, *shape), dtype=torch.float32, device=dev)
+        seg_all = torch.empty((B, *shape), dtype=torch.uint8 if labels_u8 else torch.float32, device=dev)
+        nstreams = max(1, min(int(streams), B))
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams(nstreams) if nstreams > 1 else [main]
+        if nstreams > 1:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            for q in range(nstreams):
+                side[q].wait_event(fork)
+        params = []
+        for b, ((_img, seg, seeds), key) in enumerate(zip(items, keys)):
+            with torch.cuda.stream(side[b % nstreams]):
+                got = self._pipeline_keyed(seg, seeds, key & 0xFFFFFFFFFFFFFFFF, scale01, labels_u8, out=out_all[b],
+                                           seg_out=seg_all[b])
+            if got is None:
+                return None
+            params.append(got[3])
+        if nstreams > 1:
+            for q in range(nstreams):
+                join = torch.cuda.Event()
+                join.record(side[q])
+                main.wait_event(join)
+        return out_all, seg_all, [None] * B, params
 
     def _side_streams(self, n):
         cur = self.__dict__.setdefault("_batch_streams", [])

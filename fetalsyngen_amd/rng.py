@@ -10,8 +10,13 @@ The reference draws them with `torch.randn(shape, device=device)` from the globa
                generator (so runs are still reproducible under `torch.manual_seed`), nothing else
                touches the host.  `fsg_randn_f32` regenerates the identical field for checking.
 
+  "keyed":     (fetalsyngen_amd/keyed.py) a sample is a function of its 64-bit key: every draw, small and large, from
+               Philox4x32-10 under that key, inside one native call.  Where the fused keyed path does not apply (image as
+               intensity prior, SR-artifact stages, genparams, stage-by-stage API) the global generators are seeded from
+               the key and the sample is made as in "device" mode.
+
 All SMALL draws (GMM tables, coarse displacement grid, bias grid, scalars) use numpy's / torch's CPU
-global generators with the reference's calls in the reference's order in both modes.
+global generators with the reference's calls in the reference's order in the first two modes.
 """
 from __future__ import annotations
 
@@ -21,7 +26,7 @@ import os
 import torch
 
 _MODE = os.environ.get("FSG_RNG", "device")
-_VALID = ("reference", "device")
+_VALID = ("reference", "device", "keyed")
 
 
 def get_mode() -> str:

@@ -28,9 +28,31 @@ def sample_key(base_seed: int, index: int) -> int:
     return splitmix64(splitmix64(base_seed & _M64) ^ (index & _M64))
 
 
+_PENDING_KEY = [None]
+
+
+def take_key():
+    """The key of the sample announced by the last `seed_for_sample` / `announce_key` call, handed out once (keyed mode:
+    `FetalSynthGen._pipeline` picks it up when the caller passes no explicit key)."""
+    k, _PENDING_KEY[0] = _PENDING_KEY[0], None
+    return k
+
+
+def announce_key(base_seed: int, index: int) -> int:
+    """Keyed mode's `seed_for_sample`: the sample's key without re-seeding the global generators (an MT19937 re-seed costs
+    ~10 us, more than the rest of a keyed sample's Python side)."""
+    k = _PENDING_KEY[0] = sample_key(base_seed, index)
+    return k
+
+
 def seed_for_sample(base_seed: int, index: int) -> int:
     """Seed numpy's and torch's CPU global generators for one sample; returns the key."""
     k = sample_key(base_seed, index)
+    return seed_from_key(k)
+
+
+def seed_from_key(k: int) -> int:
+    _PENDING_KEY[0] = k
     np.random.seed(k & 0xFFFFFFFF)
     # CPU generator only: torch.manual_seed() would also walk every accelerator backend's lazy
     # seeding hook (~0.1 ms per call); all host draws of this package use the CPU generator.

@@ -33,6 +33,7 @@ extern "C" {
 #define FSG_E_BADARG (-1)   /* null pointer / non-positive size / bad enum */
 #define FSG_E_TOOBIG (-2)   /* size exceeds what the kernel indexes (2^31-1 voxels per volume) */
 #define FSG_E_ALIGN  (-3)   /* pointer not aligned as the kernel requires */
+#define FSG_E_NOTABLE (-4)  /* keyed mode: a tap table this sample needs was not registered (fsg_keyed_set_table) */
 
 /* One output sample of a separable linear resample along one axis:
  * value = w_lo * src[lo] + w_hi * src[hi].  lo < 0 marks "outside" (result 0 for the voxel). */
@@ -447,7 +448,19 @@ typedef struct fsg_sample_plan {
   /* optional: the deformed labels as uint8 (needs seg_in_u8; seg_out may then be NULL): the device-resident streaming hand-over
    * (reference data/datasets.py:315-323 converts the labels after the fact) without a conversion pass */
   uint8_t* seg_out_u8;
+  /* optional stage trace (measurement only): trace_events = trace_cap hipEvent_t handles (fsg_event_create), trace_ids =
+   * trace_cap + 1 ints.  An event is recorded before the first launch (id FSG_ST_BEGIN) and after every launch of the
+   * sample (id = the FSG_ST_* of that launch); trace_ids[trace_cap] receives the number of events recorded.  The time
+   * between two consecutive events is the later one's launch plus one barrier packet (each record is one). */
+  void** trace_events;
+  int32_t* trace_ids;
+  int32_t trace_cap;
 } fsg_sample_plan;
+enum {
+  FSG_ST_BEGIN = 0, FSG_ST_UPLOAD = 1, FSG_ST_DRAW = 2, FSG_ST_HEAD = 3, FSG_ST_FLOORMIN = 4, FSG_ST_WARP = 5, FSG_ST_BLUR_X = 6,
+  FSG_ST_BLUR_Y = 7, FSG_ST_BLUR_Z = 8, FSG_ST_BLUR_YZ = 9, FSG_ST_K7 = 10, FSG_ST_K9A = 11, FSG_ST_K9B = 12, FSG_ST_GMM = 13,
+  FSG_ST_ROWS = 14, FSG_ST_POINTWISE = 15, FSG_ST_BLUR_RS_X = 16, FSG_ST_BLUR_RS_YZ = 17, FSG_ST_COUNT = 18
+};
 int fsg_sample_run(const fsg_sample_plan* plan_host, void* stream);
 /* Layout check for FFI mirrors of the struct: which = 0 -> sizeof(fsg_sample_plan); 1 / 2 / 3 / 4 -> offsetof blur_taps / out /
  * seg_in_u8 / ws_seq; anything else -> -1.  Callable without a GPU. */
@@ -469,13 +482,99 @@ enum {
   FSG_PLAN_I_NOISE_STREAM = 48, FSG_PLAN_I_SCALE01 = 49, FSG_PLAN_I_WS0 = 50, FSG_PLAN_I_WS1 = 51, FSG_PLAN_I_WS_LOW = 52,
   FSG_PLAN_I_WS_ROWS = 53, FSG_PLAN_I_ROW_STRIDE = 54, FSG_PLAN_I_MM8 = 55, FSG_PLAN_I_MM8_PRESET = 56, FSG_PLAN_I_OUT = 57,
   FSG_PLAN_I_EV_BEGIN = 58, FSG_PLAN_I_EV_END = 59, FSG_PLAN_I_MM_SLOTS = 60, FSG_PLAN_I_MM_NSLOTS = 61, FSG_PLAN_I_ARENA_HOST = 62,
-  FSG_PLAN_I_ARENA_DEV = 63, FSG_PLAN_I_ARENA_BYTES = 64, FSG_PLAN_I_OVERLAP = 65, FSG_PLAN_I_WS_SEQ = 66, FSG_PLAN_I_SEG_OUT_U8 = 67, FSG_PLAN_I_COUNT = 68
+  FSG_PLAN_I_ARENA_DEV = 63, FSG_PLAN_I_ARENA_BYTES = 64, FSG_PLAN_I_OVERLAP = 65, FSG_PLAN_I_WS_SEQ = 66, FSG_PLAN_I_SEG_OUT_U8 = 67,
+  FSG_PLAN_I_TRACE_EVENTS = 68, FSG_PLAN_I_TRACE_IDS = 69, FSG_PLAN_I_TRACE_CAP = 70, FSG_PLAN_I_COUNT = 71
 };
 enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_GAMMA = 15, FSG_PLAN_F_NOISE_STD = 16, FSG_PLAN_F_COUNT = 17 };
 #define FSG_PLAN_TAPS_STRIDE 132
 int fsg_sample_plan_pack(fsg_sample_plan* plan, const int64_t* iv, int niv, const double* fv, int nfv, const float* taps);
 int fsg_sample_pack_run(const int64_t* iv, int niv, const double* fv, int nfv, const float* taps, void* stream);
 int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams);
+
+/* ---- keyed mode: every per-sample draw from a counter-based generator keyed (base_seed, sample index) --------------------
+ * The reference draws a sample's ~30 scalars and its small tensors from numpy's / torch's GLOBAL generators, one Python call
+ * each, in an order that is part of its behaviour (rand_gmm.py:82-85,:120-148, affine_nonrigid.py:140-145,
+ * :248-263,:284,:303-318, synthseg.py:263-265,:157-176,:63-78,:218-232).  `rng="reference"` / `"device"` replay that tape on
+ * the host (~100 interpreter round trips per sample).  Keyed mode keeps the DISTRIBUTIONS and the arithmetic that turns draws
+ * into parameters, but takes every uniform / normal from Philox4x32-10 under the sample's 64-bit key (a fixed counter per
+ * draw, so gates do not shift later draws): the scalars are drawn in C inside fsg_keyed_sample_run, the small tensors (GMM
+ * tables, coarse displacement grid, bias grid) by a one-launch device kernel straight into the sample's parameter block, the
+ * two large fields in the kernels that consume them (as in "device" mode).  The host hands over pointers and the key.
+ * A sample depends on its key only -- not on the process, the GPU count or what ran before ("(base_seed,
+ * sample_index) keyed RNG").  Parity: fsg_keyed_draws exports what was drawn; tests feed it to the oracle.
+ */
+typedef struct fsg_keyed_config {
+  int32_t shape[3];
+  int32_t size[3];                 /* SpatialDeformation(size=...)                                   */
+  double resolution[3];
+  int32_t min_subclusters, max_subclusters, meta_labels;   /* ImageFromSeeds; meta_labels <= 4       */
+  int32_t nlabels;                 /* max(seed_labels) + 1 <= 256                                    */
+  int32_t n_seed_labels;           /* len(seed_labels) == len(generation_classes) <= 256             */
+  int32_t tie_classes;             /* generation_classes != seed_labels (rand_gmm.py:139-145)        */
+  uint8_t seed_labels[256];
+  uint8_t generation_classes[256];
+  double deform_prob, flip_prb, max_rotation, max_shear, max_scaling;
+  int32_t nonlinear;
+  double nonlin_scale_min, nonlin_scale_max, nonlin_std_max;
+  double gamma_prob, gamma_std;
+  double bias_prob, bf_scale_min, bf_scale_max, bf_std_min, bf_std_max;
+  double resample_prob, min_resolution, max_resolution;
+  double noise_prob, noise_std_min, noise_std_max;
+} fsg_keyed_config;
+
+typedef struct fsg_keyed_draws {
+  uint64_t key;
+  int32_t subclusters[4];          /* mlabel m+1 -> number of sub-clusters                           */
+  int32_t ntab;
+  int32_t deform_active, flip;
+  double rotations[3], shears[3], scalings[3];
+  float A[9];
+  double c2[3];
+  int32_t nonlinear;
+  double nonlin_scale, nonlin_std;
+  int32_t field_dims[3];
+  int32_t gamma_active;
+  double gamma;
+  int32_t bias_active;
+  double bf_scale, bf_std;
+  int32_t bias_dims[3];
+  int32_t resample_active;
+  double spacing, u_std, stds[3];
+  int32_t low_shape[3];
+  int32_t blur_ntaps[3];
+  int32_t noise_active;
+  double noise_std;
+  float noise_std32;
+  /* byte offsets into the sample's device parameter block of what the draw kernel writes there */
+  int32_t off_mm8, off_slots, off_mus, off_sigmas, off_bias, off_field, block_bytes;
+} fsg_keyed_draws;
+
+enum { FSG_KT_RESAMPLE = 0, FSG_KT_BACK = 1, FSG_KT_FIELD = 2, FSG_KT_BIAS = 3 };
+/* Host-only object (no HIP call, usable without a GPU).  *ctx receives the handle. */
+int fsg_keyed_create(const fsg_keyed_config* cfg, void** ctx);
+int fsg_keyed_destroy(void* ctx);
+/* Registers the DEVICE tap table of (kind, axis, n): FSG_KT_RESAMPLE / FSG_KT_BACK: n = low-res size along `axis`;
+ * FSG_KT_FIELD / FSG_KT_BIAS: n = coarse grid size along `axis`.  The tables are the ones the other modes use (built by the
+ * host mirror with the reference's own torch calls, utils/generation.py:315-363, synthseg.py:84-102), so sampling positions
+ * stay bit-identical.  A sample that needs an unregistered table fails with FSG_E_NOTABLE. */
+int fsg_keyed_set_table(void* ctx, int kind, int axis, int n, const fsg_tap* table_dev);
+/* Bytes of the per-sample device parameter block for the largest grids this configuration can draw. */
+int64_t fsg_keyed_block_bytes(void* ctx);
+/* Host draws of the sample `key` (no device work): what fsg_keyed_sample_run will use. */
+int fsg_keyed_draw(void* ctx, uint64_t key, fsg_keyed_draws* out);
+/* One sample: draws + the draw kernel + fsg_sample_run's launch sequence.  iv (int64): FSG_KEYED_I_*.
+ * bank: FSG_KEYED_I_BANK + 4 * (n_sub - min_subclusters) + (mlabel - 1) -> uint8 seed volume of (n_sub, mlabel).
+ * draws_out may be NULL. */
+enum {
+  FSG_KEYED_I_KEY = 0, FSG_KEYED_I_OUT = 1, FSG_KEYED_I_SEG_OUT = 2, FSG_KEYED_I_SEG_OUT_U8 = 3, FSG_KEYED_I_SEG_IN = 4,
+  FSG_KEYED_I_SEG_IN_U8 = 5, FSG_KEYED_I_BLOCK = 6, FSG_KEYED_I_WS0 = 7, FSG_KEYED_I_WS1 = 8, FSG_KEYED_I_WS_LOW = 9,
+  FSG_KEYED_I_WS_ROWS = 10, FSG_KEYED_I_ROW_STRIDE = 11, FSG_KEYED_I_SCALE01 = 12, FSG_KEYED_I_TRACE_EVENTS = 13,
+  FSG_KEYED_I_TRACE_IDS = 14, FSG_KEYED_I_TRACE_CAP = 15, FSG_KEYED_I_BANK = 16, FSG_KEYED_I_EV_BLUR_BEGIN = 16 + 64,
+  FSG_KEYED_I_EV_BLUR_END = 16 + 65, FSG_KEYED_I_COUNT = 16 + 66
+};
+int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws* draws_out, void* stream);
+/* The draw kernel alone (tests): fills the parameter block of `draws` at block_dev. */
+int fsg_keyed_fill_block(void* ctx, const fsg_keyed_draws* draws, void* block_dev, void* stream);
 
 /* Releases the library-owned side streams / events of the opt-in head overlap (fsg_sample_plan::overlap); they otherwise
  * live for the life of the process.  Synchronise the launch streams first.  No reference counterpart (the reference owns

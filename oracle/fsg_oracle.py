@@ -320,7 +320,7 @@ class Config:
 
 
 def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_gmm=None, noise_lowres=None,
-               keep_stages=False, image=None):
+               keep_stages=False, image=None, draws=None):
     """One `FetalSynthGen.sample` + the dataset's final [0,1] scaling, drawing from the
     numpy / torch GLOBAL generators in the reference's order
     (model.py:231-276 -> rand_gmm.py:82-85,:120-148 -> affine_nonrigid.py:140-145,:248-263,
@@ -332,7 +332,15 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     callable (shape)->tensor, invoked at the point of the draw order where the field is
     needed (the low-res shape is only known mid-way, and a callable may itself consume
     the torch generator exactly like the product's key draw does).
+    `draws`: when given, NOTHING is drawn from the global generators: every stochastic input of the sample is taken from
+    this dict (keyed mode of the HIP path: the product exports what it drew, the oracle runs the reference's arithmetic on
+    it) -- "m2s" {mlabel: n_sub}, "mus" / "sigmas" (float32 tensors), "deform" None | {"flip", "A" (3,3) float32, "c2" (3,)
+    float64, "f_small" float32 | None}, "gamma" None | float, "bias" None | float32 grid (already scaled by its std),
+    "resample" None | {"spacing", "u_std"}, "noise_std" None | float64; the two large fields through noise_gmm /
+    noise_lowres, which are then mandatory.
     Returns dict(out, seg, scaled, params, stages)."""
+    if draws is not None:
+        return _run_sample_injected(cfg, segmentation, seed_volumes, draws, noise_gmm, noise_lowres, keep_stages)
     st = {}
     if seed_volumes is not None:
         lo_s, hi_s = cfg.subclusters
@@ -436,3 +444,56 @@ def run_sample(cfg: Config, segmentation: torch.Tensor, seed_volumes, *, noise_g
     out = resize_back(out, factors)
     return {"out": out, "seg": seg, "scaled": scale01(out), "params": params, "stages": st if keep_stages else None,
             "image": image_def}
+
+
+
+def _run_sample_injected(cfg: Config, segmentation, seed_volumes, draws, noise_gmm, noise_lowres, keep_stages):
+    """`run_sample` with every draw supplied (see its `draws` argument): the same stage functions in the same order."""
+    st = {}
+    m2s = {int(m): int(n) for m, n in draws["m2s"].items()}
+    seeds = None
+    for m in sorted(m2s):
+        v = torch.as_tensor(np.asarray(seed_volumes[m2s[m]][m])).clone()
+        seeds = v if seeds is None else seeds + v
+    seeds = seeds.long()
+    mus, sigmas = draws["mus"], draws["sigmas"]
+    z = noise_gmm(tuple(seeds.shape)) if callable(noise_gmm) else noise_gmm
+    out = gmm_image(seeds, mus, sigmas, z)
+    params = {"mlabel2subclusters": m2s, "mus": mus, "sigmas": sigmas}
+    st["gmm"] = out
+
+    shape = tuple(out.shape)
+    seg, coords, flip = segmentation, None, False
+    dd = draws.get("deform")
+    if dd is not None:
+        flip = bool(dd["flip"])
+        field = nonlinear_field(dd["f_small"], shape) if dd.get("f_small") is not None else None
+        ii, jj, kk, margins = deformation_coords(shape, cfg.size, dd["A"], dd["c2"], field)
+        coords = (ii, jj, kk)
+        params.update(A=dd["A"], c2=dd["c2"], margins=margins)
+    params["flip"] = flip
+    out, seg = apply_deformation(out, seg, coords, flip)
+    st["warped"] = out
+
+    gamma = draws.get("gamma")
+    if gamma is not None:
+        out = gamma_transform(out, float(gamma))
+    params["gamma"] = gamma
+    st["gamma"] = out
+    if draws.get("bias") is not None:
+        out = bias_multiply(out, draws["bias"])
+    st["bias"] = out
+
+    factors, rs = None, draws.get("resample")
+    if rs is not None:
+        spacing = np.array([1.0, 1.0, 1.0]) * float(rs["spacing"])
+        out, factors = resample_down(out, cfg.resolution, spacing, float(rs["u_std"]))
+    st["resampled"] = out
+    nstd = draws.get("noise_std")
+    if nstd is not None:
+        zl = noise_lowres(tuple(out.shape)) if callable(noise_lowres) else noise_lowres
+        out = add_noise(out, np.array([nstd], dtype=np.float64), zl)
+    st["noisy"] = out
+    out = resize_back(out, factors)
+    return {"out": out, "seg": seg, "scaled": scale01(out), "params": params, "stages": st if keep_stages else None,
+            "image": None}
