@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-volumes", type=int, default=32, help="config3: volumes in the batch dealt i %% N")
     ap.add_argument("--stream-volumes", type=int, default=2000, help="config5: volumes streamed per rank and mode")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the samples are spread over (round robin)")
+    ap.add_argument("--tune", type=int, default=0, help="fsg_set_tuning flags (A/B runs, e.g. 16384 = unfused blur + K7)")
     ap.add_argument("--dry-plan", action="store_true", help="host plans only, no GPU (launcher test / host-cost probe)")
     return ap.parse_args(argv)
 
@@ -463,6 +464,8 @@ def run(args, rank, world, local):
     from fetalsyngen_amd.phantom import make_seed_volumes
 
     _lib.load()  # fail loudly if the HIP library is missing
+    if args.tune:
+        _lib.load().fsg_set_tuning(args.tune)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
     if os.environ.get("FSG_BENCH_SHARE_GPU0"):  # rehearsal of the N>1 path on a 1-GPU box: every rank on cuda:0
@@ -604,7 +607,8 @@ def run(args, rank, world, local):
         "config": {"workload": f"BASELINE configs[1]: single {args.size}^3 label volume per step, full path, all gates on",
                    "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation (and its cached uint8 copy, which the label gather reads) resident in HBM",
                    "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
-                   "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams},
+                   "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams,
+                   **({"tuning_flags": args.tune} if args.tune else {})},
         "roofline": {"bound": "hbm",
                      "kernel": "separable 3-pass blur = x pass (blur_strided_v4) + fused y,z pass (blur_yz_fused_kernel), "
                                "HIP events on the launch stream around the blur launches of every 4th timed sample (rank 0)",

@@ -217,6 +217,10 @@ SIGNATURES = {
     "fsg_sample_run_batch": [C.POINTER(SamplePlan), I, C.POINTER(C.c_void_p), I],
     "fsg_cast_f32_to_f16": [P, SZ, P, P],
     "fsg_pipeline_teardown": [],
+    "fsg_blur_resample_supported": [I, I, I, I, I, I, I, I, I],
+    "fsg_blur_resample_x_f32": [P, I, I, I, P, I, C.POINTER(C.c_float), I, P, P],
+    "fsg_blur_resample_yz_noise_f32": [P, I, I, I, P, P, I, I, C.POINTER(C.c_float), I, C.POINTER(C.c_float), I, I, P, U64, U64,
+                                       F, P, P],
     "fsg_keyed_create": [C.POINTER(KeyedConfig), C.POINTER(C.c_void_p)],
     "fsg_keyed_destroy": [P],
     "fsg_keyed_set_table": [P, I, I, I, P],

@@ -186,6 +186,9 @@ int draw(const KeyedCtx& C, uint64_t key, fsg_keyed_draws& d) {
 }
 
 // ---- the draw kernel -------------------------------------------------------------------------------------------------------
+// order-preserving keys of +inf / -inf (fsg_f2key): what fsg_minmax_init writes
+constexpr int32_t KEY_POS_INF = 0x7F800000, KEY_NEG_INF = (int32_t)0x807FFFFF;
+
 struct DrawK {
   uint64_t key;
   int32_t* mm8;
@@ -212,10 +215,10 @@ __device__ __forceinline__ float keyed_uniform(uint64_t key, uint64_t stream, ui
 __global__ __launch_bounds__(256) void keyed_draw_kernel(const DrawK P) {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    if (tid < 8) P.mm8[tid] = tid < 4 ? 0x7F800000 : (int32_t)0xFF7FFFFF ^ 0x7FFFFFFF;
+    if (tid < 8) P.mm8[tid] = tid < 4 ? KEY_POS_INF : KEY_NEG_INF;
     for (int q = tid; q < FSG_MM_NSLOTS * FSG_MM_SLOT_STRIDE; q += 256) {
       const int f = q % FSG_MM_SLOT_STRIDE;
-      P.slots[q] = f == 0 ? 0x7F800000 : (f == 1 ? ((int32_t)0xFF7FFFFF ^ 0x7FFFFFFF) : 0);
+      P.slots[q] = f == 0 ? KEY_POS_INF : (f == 1 ? KEY_NEG_INF : 0);
     }
     __shared__ float s_mu[256];
     float sg = 0.f;

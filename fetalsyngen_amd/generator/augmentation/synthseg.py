@@ -73,9 +73,18 @@ class RandResample(RandTransform):
         p = self.plan(output.shape, input_resolution, genparams)
         if not p.active:
             return output, None, {"spacing": None}
-        blurred = self.blur(output, p.stds)
-        small = K.resample_noise(blurred.contiguous(), K.DeviceTables(p.tabs, output.device))
+        small = self.blur_resample(output.contiguous(), p.stds, K.DeviceTables(p.tabs, output.device))
         return small, p.factors, {"spacing": p.spacing.tolist()}
+
+    @classmethod
+    def blur_resample(cls, output, stds, tabs, **noise):
+        """Blur + down-sampling (+ the noise epilogue): the fused pair of launches (csrc/fsg_blur_rs.hip) where the
+        configuration allows -- the kernels `FetalSynthGen.sample` runs -- else the three blur passes and K7."""
+        if all(s_ > 0 for s_ in stds):
+            small = K.blur_resample(output, tabs, [T.gaussian_taps(float(s_)) for s_ in stds], **noise)
+            if small is not None:
+                return small
+        return K.resample_noise(cls.blur(output, stds).contiguous(), tabs, **noise)
 
     def resize_back(self, output_resized, factors):
         """Zoom by 1/factors and divide by the global max (ref :109-114): two launches, the zoomed

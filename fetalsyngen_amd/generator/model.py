@@ -1261,10 +1261,10 @@ class FetalSynthGen:
             f = nplan.field if nplan.active else None
             z = f.device_tensor(dev) if (f is not None and f.host is not None) else None
             if rplan.active:
-                blurred = self.resampled.blur(output, rplan.stds)
-                low = K.resample_noise(blurred, rs_tabs, noise_std=nplan.std32 if nplan.active else 0.0, noise=z,
-                                       seed=(f.seed if (f is not None and f.host is None) else None),
-                                       stream_id=f.stream_id if f is not None else 0)
+                low = self.resampled.blur_resample(output.contiguous(), rplan.stds, rs_tabs,
+                                                   noise_std=nplan.std32 if nplan.active else 0.0, noise=z,
+                                                   seed=(f.seed if (f is not None and f.host is None) else None),
+                                                   stream_id=f.stream_id if f is not None else 0)
                 mm2 = K.zoom_minmax(low, back_tabs, mm=mm8[3:5])
                 output = K.zoom_normalise(low, back_tabs, mm2, mode=1 if fuse_scale else 0)
             else:

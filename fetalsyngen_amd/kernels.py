@@ -548,6 +548,35 @@ def blur_yz(x, taps_y: np.ndarray, taps_z: np.ndarray):
     return out
 
 
+def blur_resample(x, tabs: DeviceTables, taps, noise_std=0.0, noise=None, seed=None, stream_id=0, keep_mid=False):
+    """K6 + K7 (+ K8) as the fused pair of launches (fsg_blur_resample_x_f32, fsg_blur_resample_yz_noise_f32): `taps` = the
+    three per-axis Gaussian tap arrays.  None when the configuration is outside the fused kernels' domain."""
+    _need_gpu(x, noise)
+    n0, n1, n2 = _dims3(_f32(x))
+    m0, m1, m2 = tabs.lengths
+    tp = [np.ascontiguousarray(t, dtype=np.float32) for t in taps]
+    lib = _lib.load()
+    if not lib.fsg_blur_resample_supported(n0, n1, n2, m0, m1, m2, len(tp[0]), len(tp[1]), len(tp[2])):
+        return None
+    fp = C.POINTER(C.c_float)
+    mid = torch.empty((m0, n1, n2), dtype=F32, device=x.device)
+    out = torch.empty((m0, m1, m2), dtype=F32, device=x.device)
+    tx, ty, tz = tabs.ptrs
+    _lib.check(lib.fsg_blur_resample_x_f32(_p(x), n0, n1, n2, tx, m0, tp[0].ctypes.data_as(fp), len(tp[0]), _p(mid), _stream(x)),
+               "fsg_blur_resample_x_f32")
+    mode = 0
+    if noise is not None:
+        if _f32(noise).numel() != out.numel():
+            raise ValueError("noise size")
+        mode = 1
+    elif seed is not None:
+        mode = 2
+    _lib.check(lib.fsg_blur_resample_yz_noise_f32(_p(mid), m0, n1, n2, ty, tz, m1, m2, tp[1].ctypes.data_as(fp), len(tp[1]),
+                                                  tp[2].ctypes.data_as(fp), len(tp[2]), mode, _p(noise), seed or 0, stream_id,
+                                                  float(noise_std), _p(out), _stream(x)), "fsg_blur_resample_yz_noise_f32")
+    return (out, mid) if keep_mid else out
+
+
 def reduce_minmax(x) -> torch.Tensor:
     _need_gpu(x)
     mm = new_minmax(x.device)

@@ -82,6 +82,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
 #define FSG_TUNE_SLAB_ZOOM 8192 /* the slab zoom kernel also for the noise epilogues (default there: tile kernel) */
 #define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
+#define FSG_TUNE_NO_BLUR_RS 16384 /* fsg_sample_run: blur x3 + K7 as separate launches instead of the fused blur+resample pair */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);
 /* Work shape of the fused warp kernel (speed only, results identical): 0 = 4x4 rows x 64 voxels per lockstep step,
@@ -490,6 +491,25 @@ enum { FSG_PLAN_F_A = 0, FSG_PLAN_F_CENTRE = 9, FSG_PLAN_F_C2 = 12, FSG_PLAN_F_G
 int fsg_sample_plan_pack(fsg_sample_plan* plan, const int64_t* iv, int niv, const double* fv, int nfv, const float* taps);
 int fsg_sample_pack_run(const int64_t* iv, int niv, const double* fv, int nfv, const float* taps, void* stream);
 int fsg_sample_run_batch(const fsg_sample_plan* plans, int nplans, void* const* streams, int nstreams);
+
+/* ---- K6 + K7 (+ K8) fused per axis (csrc/fsg_blur_rs.hip) -----------------------------------------------------------
+ * RandResample.__call__ (generator/augmentation/synthseg.py:50-107) = gaussian_blur_3d (utils/generation.py:84-110) then the
+ * axis-aligned trilinear down-sampling (synthseg.py:84-104 -> utils/generation.py:227-278), RandNoise after it (synthseg.py:
+ * 230-233).  Blur and resampling are separable linear operators, so per axis they combine into one FIR with position-dependent
+ * coefficients (w_lo k[.] + w_hi k[. - 1]) evaluated for the m low-res outputs only; the blurred full-resolution volume is
+ * never formed.  Two launches: x (reads N, writes N m0/n0), then y + z + noise (reads N m0/n0, writes M).  Results equal
+ * the unfused sequence (fsg_blur_axis_* x3, fsg_resample_noise_f32) up to float32 rounding of a re-ordered linear map --
+ * within the blur's own tolerance (atol 1e-3 on the 0..255 scale).  Zero-padded un-renormalised borders, outputs whose
+ * position is outside (0, n-1] are 0 (lo < 0 in the table), noise and the clamp at 0 after, as in the reference.
+ * taps: odd counts 3..17 (radius 1..8) on all three axes; n2 % 4 == 0, n2 <= 512; otherwise FSG_E_ALIGN (callers then use
+ * the unfused entry points).  fsg_blur_resample_supported: 1 when both launches accept the configuration (no GPU call). */
+int fsg_blur_resample_supported(int n0, int n1, int n2, int m0, int m1, int m2, int ntaps_x, int ntaps_y, int ntaps_z);
+int fsg_blur_resample_x_f32(const float* src, int n0, int n1, int n2, const fsg_tap* tx, int m0, const float* taps_host,
+                            int ntaps, float* dst, void* stream);
+int fsg_blur_resample_yz_noise_f32(const float* src, int m0, int n1, int n2, const fsg_tap* ty, const fsg_tap* tz, int m1,
+                                   int m2, const float* taps_y_host, int ntaps_y, const float* taps_z_host, int ntaps_z,
+                                   int noise_mode, const float* noise, uint64_t seed, uint64_t stream_id, float noise_std,
+                                   float* dst, void* stream);
 
 /* ---- keyed mode: every per-sample draw from a counter-based generator keyed (base_seed, sample index) --------------------
  * The reference draws a sample's ~30 scalars and its small tensors from numpy's / torch's GLOBAL generators, one Python call

@@ -260,6 +260,62 @@ def test_blur_fast_paths_match_oracle_and_properties(K):
         assert (o[0] < 0.75).all() and (o[-1] < 0.75).all()
 
 
+def test_blur_resample_fused_pair_equals_unfused_and_oracle(K):
+    """K6 + K7 + K8 as the fused pair of launches (csrc/fsg_blur_rs.hip: blur and down-sampling of an axis as one FIR with
+    position-dependent coefficients) against (a) the unfused HIP sequence, (b) the oracle's gaussian_blur_3d +
+    fast_3D_interp_torch restatement (reference utils/generation.py:84-110, :227-278; synthseg.py:78-105, :230-233).
+    A re-ordered linear map in float32: the blur's tolerance (atol 1e-3 on 0..255)."""
+    from fetalsyngen_amd import tables as T
+
+    rs = np.random.RandomState(5)
+    cases = [((64, 56, 72), (0.5, 0.5, 0.5), 0.74, 0.3), ((64, 56, 72), (0.5, 0.5, 0.5), 1.5, 0.9),
+             ((48, 40, 64), (0.5, 0.5, 0.5), 0.55, 0.0), ((96, 96, 96), (0.5, 0.5, 0.5), 1.1, 0.5),
+             ((40, 48, 56), (0.5, 0.6, 0.7), 1.3, 0.7),   # anisotropic resolution: another radius and size per axis
+             ((33, 20, 128), (0.5, 0.5, 0.5), 0.9, 0.2), ((256, 256, 256), (0.5, 0.5, 0.5), 0.75, 0.4)]
+    for shape, res, spacing, u_std in cases:
+        x = (rs.rand(*shape) * 255).astype(np.float32)
+        x[: shape[0] // 3] *= 0.1  # structure across the volume, not only white noise
+        stds, new, _fac, tabs = T.resample_plan(shape, np.array(res), np.array([spacing] * 3), u_std)
+        taps = [T.gaussian_taps(float(s_)) for s_ in stds]
+        rt = K.DeviceTables(tabs, DEV)
+        xd = dev(x)
+        fused = K.blur_resample(xd, rt, taps)
+        assert fused is not None, (shape, spacing)
+        y = xd
+        for axis in range(3):
+            y = K.blur_axis(y, axis, taps[axis])
+        unfused = K.resample_noise(y, rt)
+        assert tuple(fused.shape) == tuple(new)
+        np.testing.assert_allclose(host(fused), host(unfused), rtol=RTOL, atol=ATOL)
+        if np.prod(shape) <= 96 ** 3:
+            ref, _f = O.resample_down(t(x), res, np.array([spacing] * 3), u_std)
+            np.testing.assert_allclose(host(fused), ref.numpy(), rtol=RTOL, atol=ATOL)
+        # with the noise epilogue: the same Philox field (indexed by the flat output quad), clamped at 0
+        a = K.blur_resample(xd, rt, taps, noise_std=40.0, seed=99, stream_id=2)
+        b = K.resample_noise(y, rt, noise_std=40.0, seed=99, stream_id=2)
+        np.testing.assert_allclose(host(a), host(b), rtol=RTOL, atol=ATOL)
+        assert float(a.min()) == 0.0
+        z = K.randn(tuple(new), 7, 2, DEV)
+        a = K.blur_resample(xd, rt, taps, noise_std=11.0, noise=z)
+        b = K.resample_noise(y, rt, noise_std=11.0, noise=z)
+        np.testing.assert_allclose(host(a), host(b), rtol=RTOL, atol=ATOL)
+    # properties at the full size: linearity, zero stays zero, a constant stays constant away from the borders
+    shape = (256, 256, 256)
+    stds, new, _fac, tabs = T.resample_plan(shape, np.array([0.5] * 3), np.array([1.2] * 3), 0.6)
+    taps = [T.gaussian_taps(float(s_)) for s_ in stds]
+    rt = K.DeviceTables(tabs, DEV)
+    x1, x2 = torch.rand(shape, device=DEV) * 255, torch.rand(shape, device=DEV) * 255
+    lhs = K.blur_resample(2 * x1 + x2, rt, taps)
+    rhs = 2 * K.blur_resample(x1, rt, taps) + K.blur_resample(x2, rt, taps)
+    np.testing.assert_allclose(host(lhs), host(rhs), rtol=1e-5, atol=2e-3)
+    assert float(K.blur_resample(torch.zeros(shape, device=DEV), rt, taps).abs().max()) == 0.0
+    ones = host(K.blur_resample(torch.ones(shape, device=DEV), rt, taps))
+    np.testing.assert_allclose(ones[4:-4, 4:-4, 4:-4], 1.0, atol=2e-6)
+    # outside the fused domain (an axis without blur: spacing <= resolution): the caller is told to use the unfused path
+    stds, new, _fac, tabs = T.resample_plan((64, 64, 64), np.array([0.5] * 3), np.array([0.5] * 3), 0.5)
+    assert K.blur_resample(torch.zeros(64, 64, 64, device=DEV), K.DeviceTables(tabs, DEV), [np.ones(1, np.float32)] * 3) is None
+
+
 def test_zoom_tile_kernel_equals_row_kernels(K):
     """The tile kernel (x-blended source rows staged once per workgroup, four outputs and one Philox block per thread) and the
     slab kernel (x, y, z stages through LDS, four consecutive outputs per lane) against the row-per-wave kernels, for every
@@ -1362,6 +1418,7 @@ def test_fast_plan_equals_field_by_field_plan(K, prob):
     lib = _lib.load()
     for mode in ("device", "reference"):
         gen = make_generator(shape, DEV, rng=mode, prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.03, 0.12))
+        gen.register_label_twin(segd, segd.to(torch.uint8))  # both plans then see the same uint8 label source
         for seed in range(6):
             np.random.seed(seed)
             torch.manual_seed(seed)

@@ -293,11 +293,12 @@ def test_keyed_samples_depend_on_the_key_only(K):
         item = ds[i]
         assert torch.equal(item["image"][0], ref[i][0].cpu()) and torch.equal(item["label"][0], ref[i][1].cpu().long())
     for kwargs in (dict(to_host=False), dict(to_host=True, depth=2), dict(to_host=False, batch_size=3, batch_streams=2)):
-        got = list(PrefetchingStream(ds, range(9), base_seed=21, **kwargs))
-        if kwargs.get("batch_size"):
-            imgs = [g["image"][b, 0] for g in got for b in range(g["image"].shape[0])]
-        else:
-            imgs = [g["image"][0].clone() for g in got]
+        imgs = []
+        for g in PrefetchingStream(ds, range(9), base_seed=21, **kwargs):  # host items are views of a pinned ring: copy now
+            if kwargs.get("batch_size"):
+                imgs += [g["image"][b, 0].clone() for b in range(g["image"].shape[0])]
+            else:
+                imgs.append(g["image"][0].clone())
         for i in range(9):
             assert torch.equal(imgs[i].cpu(), ref[i][0].cpu()), (kwargs, i)
     # schema of the params dictionary = the other modes'

@@ -96,6 +96,29 @@ rt = K.DeviceTables(rtabs, dev)
 M = int(np.prod(new))
 low = K.resample_noise(img, rt, noise_std=9.0, seed=3, stream_id=2)
 timeit(f"resample_noise_m{new[0]}", lambda: K.resample_noise(img, rt, noise_std=9.0, seed=3, stream_id=2), 4 * N + 4 * M)
+# K6 + K7 + K8 as the fused pair (csrc/fsg_blur_rs.hip), per launch
+from fetalsyngen_amd import _lib as _L
+import ctypes as _C
+for m_rs in (96, 128, args.m, 220, 250):
+    stds_r, new_r, _fr, tabs_r = T.resample_plan(shape, [0.5] * 3, [0.5 * n / m_rs] * 3, 0.5)
+    taps_r = [T.gaussian_taps(float(s_)) for s_ in stds_r]
+    if min(len(t_) for t_ in taps_r) < 3:
+        continue
+    rt_r = K.DeviceTables(tabs_r, dev)
+    Mr = int(np.prod(new_r))
+    mid = torch.empty((new_r[0], n, n), dtype=torch.float32, device=dev)
+    outr = torch.empty(tuple(new_r), dtype=torch.float32, device=dev)
+    fp = _C.POINTER(_C.c_float)
+    lib = _L.load()
+    st_ = K._stream(img)
+    def _x():
+        _L.check(lib.fsg_blur_resample_x_f32(img.data_ptr(), n, n, n, rt_r.ptrs[0], new_r[0], taps_r[0].ctypes.data_as(fp), len(taps_r[0]), mid.data_ptr(), st_), "x")
+    def _yz():
+        _L.check(lib.fsg_blur_resample_yz_noise_f32(mid.data_ptr(), new_r[0], n, n, rt_r.ptrs[1], rt_r.ptrs[2], new_r[1], new_r[2], taps_r[1].ctypes.data_as(fp), len(taps_r[1]),
+                                                    taps_r[2].ctypes.data_as(fp), len(taps_r[2]), 2, None, 3, 2, 9.0, outr.data_ptr(), st_), "yz")
+    timeit(f"blur_rs_x_m{new_r[0]}_R{len(taps_r[0])//2}", _x, 4 * N + 4 * N * new_r[0] / n)
+    timeit(f"blur_rs_yz_m{new_r[0]}_R{len(taps_r[0])//2}", _yz, 4 * N * new_r[0] / n + 4 * Mr)
+
 bt2, _ = T.zoom_tables(new, 1 / np.asarray(fac))
 zt = K.DeviceTables(bt2, dev)
 mm = K.zoom_minmax(low, zt)
