@@ -32,18 +32,16 @@
 namespace {
 
 constexpr int RS_MAXR = 8;
+
+__device__ __forceinline__ void rs_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int RS_KCAP = 2 * RS_MAXR + 1;
 struct TapsK { float w[RS_KCAP + 3]; };
 
-__device__ __forceinline__ fsg_tap rs_uniform_tap(const fsg_tap* t, int idx) {
-  const int4 v = *reinterpret_cast<const int4*>(t + idx);
-  fsg_tap r;
-  r.lo = __builtin_amdgcn_readfirstlane(v.x);
-  r.hi = __builtin_amdgcn_readfirstlane(v.y);
-  r.w_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.z));
-  r.w_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v.w));
-  return r;
-}
 
 // First output j (of m) whose lower neighbour lo[j] >= l0, for a table whose lo is non-decreasing in j (every plain
 // resampling table: positions delta + j * n / m).  Outputs with lo < 0 ("outside": value 0) sort first.  Wave-uniform
@@ -65,21 +63,45 @@ __device__ __forceinline__ float4 rs_mix4(float wl, const float4& a, float wh, c
   return make_float4(fsg_mix(wl, a.x, wh, b.x), fsg_mix(wl, a.y, wh, b.y), fsg_mix(wl, a.z, wh, b.z), fsg_mix(wl, a.w, wh, b.w));
 }
 
-// acc[d] / acc[d + 1] with a wave-uniform d: a uniform switch -- one case runs, on scalar branches
-template <int NB>
-__device__ __forceinline__ float4 rs_lerp_rows(const float4 (&acc)[NB], int d, bool same, float wl, float wh) {
-  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-#define RS_CASE(K)                                                                              \
-  case K:                                                                                       \
-    if (K < NB) out = rs_mix4(wl, acc[K < NB ? K : 0], wh, same ? acc[K < NB ? K : 0] : acc[K + 1 < NB ? K + 1 : 0]); \
-    break;
-  switch (d) {
-    RS_CASE(0) RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
-    RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15) RS_CASE(16)
-    default: break;
+// The taps of the (at most 64) outputs that follow `jb`, one per lane; output q's fields are read back with v_readlane.
+struct LaneTaps { int lo, hi; float wl, wh; };
+__device__ __forceinline__ LaneTaps rs_lane_taps(const fsg_tap* __restrict__ tab, int m, int jb) {
+  const int j = jb + (int)(threadIdx.x & 63);
+  LaneTaps t{0x7FFFFFFF, 0x7FFFFFFF, 0.f, 0.f};
+  if (j < m) {
+    const int4 v = *reinterpret_cast<const int4*>(tab + j);
+    t.lo = v.x; t.hi = v.y; t.wl = __builtin_bit_cast(float, v.z); t.wh = __builtin_bit_cast(float, v.w);
   }
-#undef RS_CASE
-  return out;
+  return t;
+}
+// One look-up for a chunk [l0, l1): the candidates jg .. jg + 63 are loaded once (one tap per lane, rs_chunk_guess +
+// rs_lane_taps: issued early, consumed after the blur); jb = first output with lo >= l0, je = first with lo >= l1 (or m), and
+// the chunk's taps are lanes (jb - jg) .. of the same registers.  Falls back to the searching routine when the guess window
+// misses (never for plain down-sampling tables: a chunk of <= 16 rows holds <= 17 outputs and the guess is within a few
+// outputs of the truth).
+struct ChunkTaps { LaneTaps t; int jb, je, shift; };
+__device__ __forceinline__ int rs_chunk_guess(int m, int l0, float f) { return min(max((int)(((float)l0 + 0.5f) * f - 0.5f) - 6, 0), m); }
+__device__ __forceinline__ ChunkTaps rs_chunk_resolve(const fsg_tap* __restrict__ tab, int m, int l0, int l1, int jg, const LaneTaps& t) {
+  const int lane = threadIdx.x & 63;
+  ChunkTaps c;
+  c.t = t;
+  const unsigned long long b0 = __ballot(c.t.lo >= l0 || jg + lane >= m), b1 = __ballot(c.t.lo >= l1 || jg + lane >= m);
+  const bool ok = b0 && b1 && (jg == 0 || !(b0 & 1ull));  // lane 0 already >= l0 with jg > 0: the guess may be too high
+  if (ok) {
+    c.jb = jg + (int)__builtin_ctzll(b0);
+    c.je = jg + (int)__builtin_ctzll(b1);
+    c.shift = c.jb - jg;
+  } else {
+    c.jb = rs_first_output(tab, m, l0, jg);
+    c.je = rs_first_output(tab, m, l1, c.jb);
+    c.t = rs_lane_taps(tab, m, c.jb);
+    c.shift = 0;
+  }
+  return c;
+}
+__device__ __forceinline__ int rs_rl(int v, int q) { return __builtin_amdgcn_readlane(v, q); }
+__device__ __forceinline__ float rs_rl(float v, int q) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), q));
 }
 
 // ---- axis 0 ------------------------------------------------------------------------------------------------------------
@@ -95,6 +117,9 @@ __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict
   if (l0 >= n) return;  // whole wave
   const bool live = c < inner4;
   const float4* s = src + (live ? c : 0);
+  const float fr = (float)m / (float)n;
+  const int jg = rs_chunk_guess(m, l0, fr);
+  const LaneTaps lt0 = rs_lane_taps(tab, m, jg);  // requested now, looked at after the blur
   float4 acc[NB];
 #pragma unroll
   for (int o = 0; o < NB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -118,21 +143,34 @@ __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict
       }
     }
   }
-  // outputs whose lower neighbour is in [l0, l0 + TL); chunk 0 also owns the "outside" outputs (lo < 0 -> 0)
-  const float f = (float)m / (float)n;
-  int j = l0 == 0 ? 0 : rs_first_output(tab, m, l0, (int)(((float)l0 - 0.5f / f) * f) - 2);
+  // Outputs whose lower neighbour is in [l0, l0 + TL); chunk 0 also owns the "outside" outputs (lo < 0 -> 0).  The tables
+  // are down-sampling tables (m <= n: positions at least one input row apart), so an input row is the lower neighbour of AT
+  // MOST ONE output: a static walk over the chunk's rows with a uniform "does an output sit here" test keeps every register
+  // index a compile-time constant (a switch over the row index is turned into a dynamic index by the optimiser and the
+  // accumulators land in scratch memory).
+  const ChunkTaps ct = rs_chunk_resolve(tab, m, l0, l0 + TL, jg, lt0);
+  const LaneTaps lt = ct.t;
+  const int jb = ct.jb - ct.shift;  // output of lane 0
   float4* d = dst + c;
-  for (; j < m; ++j) {
-    const fsg_tap a = rs_uniform_tap(tab, j);
-    if (a.lo >= l0 + TL) break;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.lo >= 0) out = rs_lerp_rows<NB>(acc, a.lo - l0, a.hi == a.lo, a.w_lo, a.w_hi);
-    if (live) d[(size_t)j * inner4] = out;
+  int q = ct.shift;
+  while (q < 63 && rs_rl(lt.lo, q) < 0) {  // outside outputs (only ever at the start of the axis)
+    if (live) d[(size_t)(jb + q) * inner4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ++q;
+  }
+#pragma unroll
+  for (int o = 0; o < TL; ++o) {
+    if (rs_rl(lt.lo, q) == l0 + o) {
+      const float wl = rs_rl(lt.wl, q), wh = rs_rl(lt.wh, q);
+      const bool same = rs_rl(lt.hi, q) == l0 + o;
+      const float4 out = rs_mix4(wl, acc[o], wh, same ? acc[o] : acc[o + 1]);
+      if (live) d[(size_t)(jb + q) * inner4] = out;
+      q = min(q + 1, 63);
+    }
   }
 }
 
 // ---- axes 1 + 2 ----------------------------------------------------------------------------------------------------------
-constexpr int RSY_TL = 4, RSY_IN = 4 * RSY_TL, RSY_ROWS = RSY_IN + 2;  // input y rows per workgroup; output rows it can emit (m <= n)
+constexpr int RSY_TL = 8, RSY_IN = 4 * RSY_TL, RSY_WROWS = RSY_TL + 1;  // input y rows per wave / workgroup; output rows a wave can emit (m <= n, + an "outside" one)
 
 struct NoiseK {
   int mode;  // 0 none, 1 pointer, 2 Philox
@@ -141,42 +179,58 @@ struct NoiseK {
   float std;
 };
 
-template <int R>
+// Four INDEPENDENT waves per workgroup, no barrier: wave w owns the input rows yin0 + 8w .. + 7 of its x-plane and everything
+// downstream of them -- the output rows whose lower neighbour they are, their z blur (in place in the wave's own LDS rows)
+// and their z resampling + noise.  Versions with workgroup-wide phases (y for the tile, barrier, z blur for the tile,
+// barrier, lerp for the tile) and with 4 rows per wave ran 2-3x slower: every phase is short and ends in a wait, so a wave
+// must carry enough rows through its own chain of waits.  The z taps of a lane's outputs stay in registers (the same for
+// every row): NQ quads of consecutive outputs per lane, m2 <= 256 NQ.
+// SAME: both axes use one tap set (the isotropic case the generator draws): Kz is not read, which halves the kernel's scalar
+// register footprint (two tap sets spill 40-77 SGPRs at R >= 4).
+template <int R, bool SAME, int NQ>
 __global__ __launch_bounds__(256) void blur_rs_yz_kernel(const float4* __restrict__ src, float* __restrict__ dst, int ny, int nz,
                                                          int m1, int m2, const fsg_tap* __restrict__ taby,
                                                          const fsg_tap* __restrict__ tabz, TapsK Ky, TapsK Kz, NoiseK NZ) {
   constexpr int RP = (R + 3) & ~3, TL = RSY_TL, NB = TL + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int inner4 = nz >> 2, pitch = nz + 2 * RP;
-  float* bufA = lds;                                   // [RSY_ROWS][pitch]  y-resampled rows, zero z halos
-  float* bufD = bufA + RSY_ROWS * pitch;               // [RSY_ROWS][nz]     z-blurred rows
-  fsg_tap* tc = reinterpret_cast<fsg_tap*>(bufD + RSY_ROWS * nz);  // [m2] z taps
-  __shared__ int s_j[5];                               // first output row of every wave's chunk; [4] = end of the tile
-  const int tx = threadIdx.x, tyc = threadIdx.y, tid = tyc * 64 + tx;
+  const int tx = threadIdx.x, tyc = threadIdx.y;
+  float* rows = lds + (size_t)tyc * RSY_WROWS * pitch;            // this wave's rows, zero z halos
   const int tiles_y = (ny + RSY_IN - 1) / RSY_IN;
   const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
   const int bx = tile / tiles_y;
   const int yin0 = (tile - bx * tiles_y) * RSY_IN;
   const size_t plane4 = (size_t)bx * ny * inner4;
-  for (int k = tid; k < m2; k += 256) tc[k] = tabz[k];
-  for (int e = tid; e < RSY_ROWS * (2 * RP / 4); e += 256) {  // zero z halos of every row of A
+  const int l0 = yin0 + tyc * TL;
+  if (l0 >= ny) return;  // whole wave; there is no barrier in this kernel
+  // requested now, looked at later: the y taps of the chunk's outputs, the z taps of this lane's outputs
+  const int jg = rs_chunk_guess(m1, l0, (float)m1 / (float)ny);
+  const LaneTaps lt0 = rs_lane_taps(taby, m1, jg);
+  int zlo[NQ][4], zhi[NQ][4];
+  float zwl[NQ][4], zwh[NQ][4];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = (tx + 64 * i) * 4 + u;
+      const int4 v = *reinterpret_cast<const int4*>(tabz + min(k, m2 - 1));
+      const bool ok = k < m2 && v.x >= 0;
+      zlo[i][u] = ok ? v.x : 0; zhi[i][u] = ok ? v.y : 0;
+      zwl[i][u] = ok ? __builtin_bit_cast(float, v.z) : 0.f;  // an "outside" output: 0 * row[0] + 0 * row[0] = 0
+      zwh[i][u] = ok ? __builtin_bit_cast(float, v.w) : 0.f;
+    }
+  for (int e = tx; e < RSY_WROWS * (2 * RP / 4); e += 64) {  // zero z halos of the wave's rows
     const int r = e / (2 * RP / 4), h = e - r * (2 * RP / 4);
-    float* row = bufA + (size_t)r * pitch;
+    float* row = rows + (size_t)r * pitch;
     reinterpret_cast<float4*>(h < RP / 4 ? row : row + RP + nz)[h < RP / 4 ? h : h - RP / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // ---- y: blur in registers, resampled rows into A ----
-  const int l0 = yin0 + tyc * TL;
-  const float f = (float)m1 / (float)ny;
-  const int jb = l0 == 0 ? 0 : rs_first_output(taby, m1, l0, (int)(((float)l0 - 0.5f / f) * f) - 2);
-  if (tx == 0) s_j[tyc] = jb;
-  if (tyc == 3 && tx == 0) {
-    const int lend = yin0 + RSY_IN;
-    s_j[4] = lend >= ny ? m1 : rs_first_output(taby, m1, lend, (int)(((float)lend - 0.5f / f) * f) - 2);
-  }
-  // (wave 3's second search is executed by the whole wave -- rs_first_output is a wave-level routine; only lane 0 stores)
-  __syncthreads();
-  const int jt0 = s_j[0], nj = min(s_j[4] - s_j[0], RSY_ROWS);
-  for (int c = tx; c < inner4; c += 64) {
+  // ---- y: blur in registers, resampled rows into the wave's LDS rows ----
+  // (every lane runs every round of this loop -- column clamped, stores guarded: the table look-up below is a wave-level
+  // routine of ballots and lane reads, and a lane that sat out would also miss jb / nrows)
+  int jb = 0, nrows = 0;
+  for (int cb = 0; cb < inner4; cb += 64) {
+    const bool live = cb + tx < inner4;
+    const int c = min(cb + tx, inner4 - 1);
     const float4* s = src + plane4 + c;
     float4 acc[NB];
 #pragma unroll
@@ -184,7 +238,7 @@ __global__ __launch_bounds__(256) void blur_rs_yz_kernel(const float4* __restric
 #pragma unroll
     for (int t = 0; t < NB + 2 * R; ++t) {
       const int l = l0 + t - R;
-      float4 v = s[(size_t)min(max(l, 0), ny - 1) * inner4];
+      float4 v = s[(size_t)min(max(l, 0), ny - 1) * inner4];  // unconditional, zeroed when outside (see blur_rs_x_kernel)
       const bool in = l >= 0 && l < ny;
       v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
 #pragma unroll
@@ -199,92 +253,130 @@ __global__ __launch_bounds__(256) void blur_rs_yz_kernel(const float4* __restric
         }
       }
     }
-    if (l0 < ny) {
-      for (int j = jb; j < m1 && j - jt0 < RSY_ROWS; ++j) {
-        const fsg_tap a = rs_uniform_tap(taby, j);
-        if (a.lo >= l0 + TL) break;
-        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.lo >= 0) out = rs_lerp_rows<NB>(acc, a.lo - l0, a.hi == a.lo, a.w_lo, a.w_hi);
-        reinterpret_cast<float4*>(bufA + (size_t)(j - jt0) * pitch + RP)[c] = out;
+    const ChunkTaps ct = rs_chunk_resolve(taby, m1, l0, l0 + TL, jg, lt0);
+    const LaneTaps lt = ct.t;
+    const int jl0 = ct.jb - ct.shift;                 // output of lane 0 of the taps
+    jb = ct.jb;
+    nrows = min(ct.je - ct.jb, RSY_WROWS);
+    int q = ct.shift;  // static walk over the chunk's rows, as in blur_rs_x_kernel
+    while (q < 63 && rs_rl(lt.lo, q) < 0) {
+      if (live && jl0 + q - jb < RSY_WROWS) reinterpret_cast<float4*>(rows + (size_t)(jl0 + q - jb) * pitch + RP)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ++q;
+    }
+#pragma unroll
+    for (int o = 0; o < TL; ++o) {
+      if (rs_rl(lt.lo, q) == l0 + o) {
+        const float wl = rs_rl(lt.wl, q), wh = rs_rl(lt.wh, q);
+        const bool same = rs_rl(lt.hi, q) == l0 + o;
+        const float4 out = rs_mix4(wl, acc[o], wh, same ? acc[o] : acc[o + 1]);
+        if (live && jl0 + q - jb < RSY_WROWS) reinterpret_cast<float4*>(rows + (size_t)(jl0 + q - jb) * pitch + RP)[c] = out;
+        q = min(q + 1, 63);
       }
     }
   }
-  __syncthreads();
-  // ---- z blur: wave w takes rows w, w + 4, ... of A into D (taps ascending with fmaf, as blur_contig_lds) ----
-  for (int r = tyc; r < nj; r += 4) {
-    const float* row = bufA + (size_t)r * pitch;
-    float4* d4 = reinterpret_cast<float4*>(bufD + (size_t)r * nz);
-    for (int q = tx; q < inner4; q += 64) {
-      float win[4 + 2 * RP];
+  rs_wave_sync();
+  // ---- per output row: z blur in place (every lane reads its windows, then the row is overwritten; taps ascending, fmaf),
+  //      then z resampling + noise + clamp of the lane's quads (one Philox block per aligned quad of the FLAT output index:
+  //      a row that does not start on a multiple of 4 takes its normals from two neighbouring blocks) ----
+  // Two rows per round: their blur windows are read before ONE wave sync and written after it, and their two Philox +
+  // Box-Muller chains (each a long run of dependent instructions) interleave in the same basic block.
+  for (int r0 = 0; r0 < nrows; r0 += 2) {
+    float o[2][2][4];  // [row of the pair][float4 of the lane: nz <= 512][component]
 #pragma unroll
-      for (int u = 0; u < (4 + 2 * RP) / 4; ++u) {
-        const float4 t = reinterpret_cast<const float4*>(row)[q + u];
-        win[4 * u] = t.x; win[4 * u + 1] = t.y; win[4 * u + 2] = t.z; win[4 * u + 3] = t.w;
-      }
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < 2; ++p) {
+      const float* row = rows + (size_t)min(r0 + p, nrows - 1) * pitch;
 #pragma unroll
-      for (int t = 0; t <= 2 * R; ++t) {
-        const float w = Kz.w[t];
+      for (int qi = 0; qi < 2; ++qi) {
+        const int qq = min(tx + 64 * qi, inner4 - 1);
+        float win[4 + 2 * RP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaf(w, win[RP - R + e + t], o[e]);
-      }
-      d4[q] = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  }
-  __syncthreads();
-  // ---- z resample + noise + clamp over the tile's contiguous output range (flat quads: one Philox block each) ----
-  const size_t obase = ((size_t)bx * m1 + jt0) * m2;
-  const size_t oend = obase + (size_t)max(nj, 0) * m2;
-  const float inv_m2 = 1.0f / (float)m2;
-  for (size_t q = (obase >> 2) + tid; (q << 2) < oend; q += 256) {
-    const size_t o0 = q << 2;
-    float v[4];
-    bool live[4];
-    const size_t first = o0 < obase ? obase : o0;
-    int rel = (int)(first - obase);
-    int jj = (int)((float)rel * inv_m2);
-    int k = rel - jj * m2;
-    if (k < 0) { --jj; k += m2; }
-    if (k >= m2) { ++jj; k -= m2; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t o = o0 + u;
-      live[u] = o >= obase && o < oend;
-      v[u] = 0.f;
-      if (live[u]) {
-        const fsg_tap cz = tc[k];
-        if (cz.lo >= 0) {
-          const float* rd = bufD + (size_t)jj * nz;
-          v[u] = fsg_mix(cz.w_lo, rd[cz.lo], cz.w_hi, rd[cz.hi]);
+        for (int u = 0; u < (4 + 2 * RP) / 4; ++u) {
+          const float4 t = reinterpret_cast<const float4*>(row)[qq + u];
+          win[4 * u] = t.x; win[4 * u + 1] = t.y; win[4 * u + 2] = t.z; win[4 * u + 3] = t.w;
         }
-        if (++k == m2) { k = 0; ++jj; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[p][qi][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+          const float w = SAME ? Ky.w[t] : Kz.w[t];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[p][qi][e] = fmaf(w, win[RP - R + e + t], o[p][qi][e]);
+        }
+        if (qi == 0 && inner4 <= 64) break;  // uniform: one float4 per lane and row
       }
     }
-    if (NZ.mode == 2) {
-      const float4 z = fsg_randn4(NZ.seed, NZ.stream_id, (uint64_t)q);
-      v[0] += NZ.std * z.x; v[1] += NZ.std * z.y; v[2] += NZ.std * z.z; v[3] += NZ.std * z.w;
-    } else if (NZ.mode == 1) {
+    rs_wave_sync();
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (live[u]) v[u] += NZ.std * NZ.noise[o0 + u];
+    for (int p = 0; p < 2; ++p) {
+      if (r0 + p < nrows) {
+        float* row = rows + (size_t)(r0 + p) * pitch;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+          if (tx + 64 * qi < inner4) reinterpret_cast<float4*>(row + RP)[tx + 64 * qi] = make_float4(o[p][qi][0], o[p][qi][1], o[p][qi][2], o[p][qi][3]);
+      }
     }
-    if (NZ.mode != 0) {
+    rs_wave_sync();
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = v[u] < 0.f ? 0.f : v[u];
-    }
-    if (live[0] && live[3] && ((((uintptr_t)dst) & 15) == 0)) {
-      *reinterpret_cast<float4*>(dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+    for (int p = 0; p < 2; ++p) {
+      if (r0 + p >= nrows) break;  // uniform
+      const float* rd = rows + (size_t)(r0 + p) * pitch + RP;
+      const size_t rbase = ((size_t)bx * m1 + jb + r0 + p) * m2;  // flat index of the row's first output
+      const int sh = (int)(rbase & 3);                           // wave-uniform misalignment against the Philox quads
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (live[u]) dst[o0 + u] = v[u];
+      for (int i = 0; i < NQ; ++i) {
+        const int k0 = (tx + 64 * i) * 4;
+        if (i > 0 && 256 * i >= m2) break;  // uniform
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fsg_mix(zwl[i][u], rd[zlo[i][u]], zwh[i][u], rd[zhi[i][u]]);
+        const size_t e0 = rbase + (size_t)k0;
+        if (NZ.mode == 2) {
+          // outputs e0 .. e0 + 3 = elements sh .. 3 of block e0 >> 2 and 0 .. sh - 1 of the next one
+          // (the next block is the NEXT LANE's own block -- its outputs start four elements further -- so it comes over by a
+          // lane shift instead of a second Philox + Box-Muller evaluation; only the last lane of the row may need its own)
+          const float4 za = fsg_randn4(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2));
+          float z[4] = {za.x, za.y, za.z, za.w};
+          if (sh) {
+            float4 zb = make_float4(__shfl_down(za.x, 1, FSG_WAVE), __shfl_down(za.y, 1, FSG_WAVE), __shfl_down(za.z, 1, FSG_WAVE),
+                                    __shfl_down(za.w, 1, FSG_WAVE));
+            // lane 63's successor is not in this wave-instruction: needed only if one of its VALID outputs reaches into it
+            const int nvalid63 = min(m2 - (63 + 64 * i) * 4, 4);  // uniform
+            if (sh + nvalid63 - 1 >= 4) {
+              if (tx == 63) zb = fsg_randn4(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2) + 1);
+            }
+            const float zz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+            if (sh == 1) { z[0] = zz[1]; z[1] = zz[2]; z[2] = zz[3]; z[3] = zz[4]; }
+            else if (sh == 2) { z[0] = zz[2]; z[1] = zz[3]; z[2] = zz[4]; z[3] = zz[5]; }
+            else { z[0] = zz[3]; z[1] = zz[4]; z[2] = zz[5]; z[3] = zz[6]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] += NZ.std * z[u];
+        } else if (NZ.mode == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < m2) v[u] += NZ.std * NZ.noise[e0 + u];
+        }
+        if (NZ.mode != 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = v[u] < 0.f ? 0.f : v[u];
+        }
+        if (k0 + 3 < m2) {  // 16-byte store, 4-byte aligned (rows start anywhere)
+          typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+          *reinterpret_cast<f4u*>(dst + e0) = f4u{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < m2) dst[e0 + u] = v[u];
+        }
+      }
     }
   }
 }
 
 size_t rs_yz_lds(int nz, int m2, int R) {
   const int RP = (R + 3) & ~3;
-  return ((size_t)RSY_ROWS * (nz + 2 * RP) + (size_t)RSY_ROWS * nz + 4 * (size_t)m2) * sizeof(float);
+  (void)m2;
+  return ((size_t)4 * RSY_WROWS * (nz + 2 * RP)) * sizeof(float);
 }
 
 template <int R>
@@ -293,8 +385,14 @@ int launch_rs_yz(const float* src, float* dst, int m0, int ny, int nz, int m1, i
   const size_t lds = rs_yz_lds(nz, m2, R);
   if (lds > 64000) return FSG_E_ALIGN;
   const unsigned tiles_y = (unsigned)((ny + RSY_IN - 1) / RSY_IN);
-  hipLaunchKernelGGL(blur_rs_yz_kernel<R>, dim3(tiles_y * (unsigned)m0), dim3(64, 4), lds, st,
-                     reinterpret_cast<const float4*>(src), dst, ny, nz, m1, m2, ty, tz, Ky, Kz, NZ);
+  bool same = true;
+  for (int t = 0; t < RS_KCAP + 3; ++t) same = same && Ky.w[t] == Kz.w[t];
+#define RS_YZ(S, Q)                                                                                            \
+  hipLaunchKernelGGL((blur_rs_yz_kernel<R, S, Q>), dim3(tiles_y * (unsigned)m0), dim3(64, 4), lds, st,             \
+                     reinterpret_cast<const float4*>(src), dst, ny, nz, m1, m2, ty, tz, Ky, S ? Ky : Kz, NZ)
+  if (m2 <= 256) { if (same) RS_YZ(true, 1); else RS_YZ(false, 1); }
+  else           { if (same) RS_YZ(true, 2); else RS_YZ(false, 2); }
+#undef RS_YZ
   FSG_RETURN_LAUNCH();
 }
 

@@ -271,7 +271,9 @@ def test_blur_resample_fused_pair_equals_unfused_and_oracle(K):
     cases = [((64, 56, 72), (0.5, 0.5, 0.5), 0.74, 0.3), ((64, 56, 72), (0.5, 0.5, 0.5), 1.5, 0.9),
              ((48, 40, 64), (0.5, 0.5, 0.5), 0.55, 0.0), ((96, 96, 96), (0.5, 0.5, 0.5), 1.1, 0.5),
              ((40, 48, 56), (0.5, 0.6, 0.7), 1.3, 0.7),   # anisotropic resolution: another radius and size per axis
-             ((33, 20, 128), (0.5, 0.5, 0.5), 0.9, 0.2), ((256, 256, 256), (0.5, 0.5, 0.5), 0.75, 0.4)]
+             ((33, 20, 128), (0.5, 0.5, 0.5), 0.9, 0.2), ((256, 256, 256), (0.5, 0.5, 0.5), 0.75, 0.4),
+             ((40, 36, 28), (0.5, 0.5, 0.5), 0.8, 0.6), ((20, 24, 12), (0.5, 0.5, 0.5), 1.4, 0.1),   # rows shorter than a wave
+             ((24, 300, 320), (0.5, 0.5, 0.5), 1.0, 0.5)]                                            # more than 256 voxels per row
     for shape, res, spacing, u_std in cases:
         x = (rs.rand(*shape) * 255).astype(np.float32)
         x[: shape[0] // 3] *= 0.1  # structure across the volume, not only white noise

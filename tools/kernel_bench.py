@@ -118,6 +118,10 @@ for m_rs in (96, 128, args.m, 220, 250):
                                                     taps_r[2].ctypes.data_as(fp), len(taps_r[2]), 2, None, 3, 2, 9.0, outr.data_ptr(), st_), "yz")
     timeit(f"blur_rs_x_m{new_r[0]}_R{len(taps_r[0])//2}", _x, 4 * N + 4 * N * new_r[0] / n)
     timeit(f"blur_rs_yz_m{new_r[0]}_R{len(taps_r[0])//2}", _yz, 4 * N * new_r[0] / n + 4 * Mr)
+    def _yz0():
+        _L.check(lib.fsg_blur_resample_yz_noise_f32(mid.data_ptr(), new_r[0], n, n, rt_r.ptrs[1], rt_r.ptrs[2], new_r[1], new_r[2], taps_r[1].ctypes.data_as(fp), len(taps_r[1]),
+                                                    taps_r[2].ctypes.data_as(fp), len(taps_r[2]), 0, None, 3, 2, 9.0, outr.data_ptr(), st_), "yz")
+    timeit(f"blur_rs_yz_nonoise_m{new_r[0]}_R{len(taps_r[0])//2}", _yz0, 4 * N * new_r[0] / n + 4 * Mr)
 
 bt2, _ = T.zoom_tables(new, 1 / np.asarray(fac))
 zt = K.DeviceTables(bt2, dev)
