@@ -754,6 +754,155 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   }
 }
 
+// ---- wave variant (r03; opt-in, FSG_TUNE_WAVE_ZOOM: bit-identical, slower than the slab kernel -- see launch1) -----------
+// Four INDEPENDENT waves per workgroup, no barrier: a wave owns ZW_ROWS consecutive output rows of one x-plane.  It forms the
+// window of x-blended source rows those outputs reference in its own LDS rows (one phase of global loads: the window is a
+// contiguous run of the two source planes), then every output is evaluated straight from that window -- two y-blends of LDS
+// values and one z-lerp, exactly the tile kernel's arithmetic (x -> y -> z, separate multiplies and adds: bit-identical to
+// fsg_tab_interp<1>) -- with the z taps of the lane's four outputs in registers.  Against the slab kernel: no y-blended row
+// is written to LDS and read back (a dependent write -> sync -> read per output row), no workgroup-wide phases (the slab
+// kernel's fixed 10-12 us per pass: taps -> barrier -> window -> barrier, profiles/r02_b_zoom_experiments.txt), and a wave
+// that waits only ever waits for its own loads.  Same lesson as csrc/fsg_blur_rs.hip's y,z kernel.
+constexpr int ZW_ROWS = 8;   // output rows per wave
+constexpr int ZW_B = 12;    // trips of the window sweep whose loads are in flight together
+constexpr int ZW_XR = 12;    // window rows a wave can hold (ZW_ROWS outputs of an up-sampling table reference <= ZW_ROWS + 1)
+
+template <int EPI>
+__global__ __launch_bounds__(256) void zoom_wave_kernel(ZoomK Z, EpiZ E) {
+  extern __shared__ __attribute__((aligned(16))) float zw_smem[];
+  const int tx = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* xs = zw_smem + (size_t)wave * ZW_XR * Z.sz;  // this wave's window: [ZW_XR][sz]
+  const int tiles_y = (Z.dy + 4 * ZW_ROWS - 1) / (4 * ZW_ROWS);
+  const int nb = gridDim.x;
+  const int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous x slabs
+  const int i = tile / tiles_y;
+  const int j0 = (tile - i * tiles_y) * 4 * ZW_ROWS + wave * ZW_ROWS;
+  if (j0 >= Z.dy) return;  // whole wave; there is no barrier in this kernel
+  const int nj = min(ZW_ROWS, Z.dy - j0);
+  int kmin_l = 0, kmax_l = 0;
+  if (EPI == EPI_NORM) zoom_mm_issue(E, kmin_l, kmax_l);  // consumed behind the window loads
+  // requested now: the y taps of the wave's rows (one per lane), the z taps of this lane's four outputs
+  int4 yt = make_int4(-1, 0, 0, 0);
+  if (tx < nj) yt = *reinterpret_cast<const int4*>(Z.ty + j0 + tx);
+  int zlo[4], zhi[4];
+  float zwl[4], zwh[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = tx * 4 + u;
+    const int4 c = *reinterpret_cast<const int4*>(Z.tz + min(k, Z.dz - 1));
+    const bool ok = k < Z.dz && c.x >= 0;
+    zlo[u] = ok ? c.x : 0; zhi[u] = ok ? c.y : 0;
+    zwl[u] = ok ? __builtin_bit_cast(float, c.z) : 0.f;  // "outside": 0 * v + 0 * v = 0
+    zwh[u] = ok ? __builtin_bit_cast(float, c.w) : 0.f;
+  }
+  const fsg_tap a = zuniform_tap(Z.tx, i);
+  int smin = yt.x >= 0 ? yt.x : 0x7FFFFFFF, smax = yt.x >= 0 ? yt.y : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    smin = min(smin, __shfl_xor(smin, o, FSG_WAVE));
+    smax = max(smax, __shfl_xor(smax, o, FSG_WAVE));
+  }
+  smin = __builtin_amdgcn_readfirstlane(smin);
+  smax = __builtin_amdgcn_readfirstlane(smax);
+  const int nrows = smax - smin + 1;
+  const bool okx = a.lo >= 0 && nrows > 0;
+  const bool fits = nrows <= ZW_XR;  // uniform; false only for tables that are not a plain zoom
+  if (okx && fits) {
+    const float* pa = Z.src + ((size_t)a.lo * Z.sy + smin) * Z.sz;
+    const float* pb = Z.src + ((size_t)a.hi * Z.sy + smin) * Z.sz;
+    const int tot = nrows * Z.sz;  // contiguous in the source: one linear, coalesced sweep
+    // ZW_B trips of the sweep at a time, every load unconditional (index clamped): all 2 ZW_B loads of a batch are in
+    // flight together.  A plain `for (e = tx; e < tot; e += 64)` is a chain of ~20 round trips to memory per wave.
+    for (int e0 = 0; e0 < tot; e0 += 64 * ZW_B) {
+      float va[ZW_B], vb[ZW_B];
+#pragma unroll
+      for (int u = 0; u < ZW_B; ++u) {
+        const int e = min(e0 + u * 64 + tx, tot - 1);
+        va[u] = pa[e];
+        vb[u] = pb[e];
+      }
+#pragma unroll
+      for (int u = 0; u < ZW_B; ++u) {
+        const int e = e0 + u * 64 + tx;
+        if (e < tot) xs[e] = fsg_mix(a.w_lo, va[u], a.w_hi, vb[u]);
+      }
+    }
+  }
+  float mnq = 0.f, den = 1.f, mx = 1.f;
+  if (EPI == EPI_NORM) {
+    float mn;
+    zoom_mm_finish(kmin_l, kmax_l, mn, mx);
+    mnq = mn / mx;
+    den = 1.0f - mnq;
+  }
+  const UniDiv ud = unidiv_make(mx);
+  const UniDiv udd = unidiv_make(den);
+  zwave_sync();
+  float lo = INFINITY, hi = -INFINITY;
+  const bool dst16 = (Z.dz & 3) == 0 && ((((uintptr_t)Z.dst) & 15) == 0);
+  const bool full = tx * 4 + 3 < Z.dz;
+  for (int jj = 0; jj < nj; ++jj) {
+    const int blo = __builtin_amdgcn_readlane(yt.x, jj), bhi = __builtin_amdgcn_readlane(yt.y, jj);
+    const float bwl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(yt.z, jj));
+    const float bwh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(yt.w, jj));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (okx && blo >= 0) {
+      if (fits) {
+        const float* xl = xs + (blo - smin) * Z.sz;
+        const float* xh = xs + (bhi - smin) * Z.sz;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float ylo = fsg_mix(bwl, xl[zlo[u]], bwh, xh[zlo[u]]);
+          const float yhi = fsg_mix(bwl, xl[zhi[u]], bwh, xh[zhi[u]]);
+          v[u] = fsg_mix(zwl[u], ylo, zwh[u], yhi);
+        }
+      } else {
+        for (int u = 0; u < 4; ++u)
+          if (tx * 4 + u < Z.dz && (zwl[u] != 0.f || zwh[u] != 0.f))
+            v[u] = zoom_slab_slow(Z.src, Z.sy, Z.sz, a, fsg_tap{blo, bhi, bwl, bwh}, fsg_tap{zlo[u], zhi[u], zwl[u], zwh[u]});
+      }
+    }
+    const size_t o0 = ((size_t)i * Z.dy + j0 + jj) * Z.dz + (size_t)tx * 4;
+    if (EPI == EPI_NORM) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#ifdef FSG_NO_UNIDIV
+        float t = v[u] / mx;
+#else
+        float t = unidiv(ud, v[u]);
+#endif
+        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : unidiv(udd, t - mnq));
+        v[u] = t;
+      }
+    }
+    if (EPI == EPI_MINMAX) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tx * 4 + u < Z.dz) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+    } else if (full && dst16) {
+      *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tx * 4 + u < Z.dz) Z.dst[o0 + u] = v[u];
+    }
+  }
+  if (EPI == EPI_MINMAX) {
+    lo = fsg_wave_min(lo);
+    hi = fsg_wave_max(hi);
+    if (tx == 0) {
+      if (E.mm_shards > 1) {  // slot by wave, not by workgroup: the four waves of a workgroup finish at different times
+        int32_t* s_ = E.mm_out + (int)((blockIdx.x * 4u + (unsigned)wave) % (unsigned)E.mm_shards) * FSG_MM_SLOT_STRIDE;
+        (void)__hip_atomic_fetch_min(&s_[0], fsg_f2key(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_max(&s_[1], fsg_f2key(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        fsg_atomic_min_key(&E.mm_out[0], lo);
+        fsg_atomic_max_key(&E.mm_out[1], hi);
+      }
+    }
+  }
+}
+
 int g_zoom_ty = 16;            // output y rows per workgroup of zoom_tile_kernel
 int g_zoom_cap = 12288;        // LDS floats for the x-blended source window (48 KB)
 
@@ -791,6 +940,20 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     }
   }
   const bool noise_epi = EPI == EPI_NOISE_PHILOX || EPI == EPI_NOISE_PTR;
+  // r03: the wave kernel (independent waves, outputs straight from the x-blended window) for the passes without a noise draw
+  // Opt-in (FSG_TUNE_WAVE_ZOOM): measured SLOWER than the slab kernel at 256^3 (K9b 36.6 vs 27.5 us at m = 171, K9a 23.7 vs 17.4:
+  // profiles/r03_c_zoom_wave_pmc.json) -- both are bound by instruction issue and LDS waits (~160 VALU + ~140 SALU per output
+  // row and wave, half of it the exact-division epilogue), and the direct form doubles the LDS bank conflicts.
+  if ((g_tuning_flags & FSG_TUNE_WAVE_ZOOM) && !noise_epi && !noise_big && Z.dz <= 256 && Z.sz <= 1024 &&
+      !(g_tuning_flags & (FSG_TUNE_GENERIC_ZOOM | FSG_TUNE_ROW_ZOOM | FSG_TUNE_TILE_ZOOM | FSG_TUNE_SLAB_ZOOM))) {
+    const size_t lds = (size_t)4 * ZW_XR * Z.sz * sizeof(float);
+    // window estimate as for the tile / slab kernels: ZW_ROWS outputs advance sy/dy source rows each (+2 for the pair and rounding)
+    if (lds <= 64000 && (long long)ZW_ROWS * Z.sy / Z.dy + 3 <= ZW_XR) {
+      const int tiles_y = (Z.dy + 4 * ZW_ROWS - 1) / (4 * ZW_ROWS);
+      hipLaunchKernelGGL(zoom_wave_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), lds, fsg_stream(stream), Z, E);
+      FSG_RETURN_LAUNCH();
+    }
+  }
   // measured at 256^3 (profiles/r02_b_zoom_experiments.txt): the slab kernel wins for the passes that store (K9b 28 vs 32.5 us);
   // the min/max pass ends every workgroup with two gated atomics, which cost the slab kernel's 4 096 workgroups more than the
   // row kernel's 2 048 (38 vs 31 us; 22 us with the atomics removed) whether or not the keys are sharded over slots

@@ -82,6 +82,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
 #define FSG_TUNE_SLAB_ZOOM 8192 /* the slab zoom kernel also for the noise epilogues (default there: tile kernel) */
 #define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
+#define FSG_TUNE_WAVE_ZOOM 32768 /* opt in: zooms without a noise draw through the wave kernel (independent waves; slower in r03) */
 #define FSG_TUNE_NO_BLUR_RS 16384 /* fsg_sample_run: blur x3 + K7 as separate launches instead of the fused blur+resample pair */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
 int fsg_set_tuning(int flags);

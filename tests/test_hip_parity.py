@@ -336,10 +336,10 @@ def test_zoom_tile_kernel_equals_row_kernels(K):
         bt, _ = T.zoom_tables(new, 1 / np.asarray(fac))
         zt = K.DeviceTables(bt, DEV)
         res = {}
-        for flag in (256, 512, 8192, 0):  # FSG_TUNE_ROW_ZOOM, FSG_TUNE_TILE_ZOOM, FSG_TUNE_SLAB_ZOOM, defaults
+        for flag in (256, 512, 8192, 32768, 0):  # FSG_TUNE_ROW_ZOOM, _TILE_ZOOM, _SLAB_ZOOM, _WAVE_ZOOM (r03, opt-in), defaults
             prev = lib.fsg_set_tuning(flag)
             try:
-                for ty in ((16,) if flag in (256, 0) else (1, 5, 16, 32)):
+                for ty in ((16,) if flag in (256, 32768, 0) else (1, 5, 16, 32)):
                     lib.fsg_zoom_set_tuning(ty, 12288)
                     low = K.resample_noise(x, rt, noise_std=9.0, seed=11, stream_id=2)
                     z = K.randn(tuple(new), 5, 6, DEV)
