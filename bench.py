@@ -158,7 +158,7 @@ def _drop_events(events):
     from fetalsyngen_amd import _lib
 
     lib = _lib.load()
-    for e0, e1, _ in events:
+    for e0, e1, *_ in events:
         lib.fsg_event_destroy(e0)
         lib.fsg_event_destroy(e1)
     events.clear()
@@ -569,26 +569,69 @@ def run(args, rank, world, local):
         tr.close()
 
     lib = _lib.load()
-    blur_total_ms, sections = 0.0, []
+    blur_total_ms, sections, lows = 0.0, [], []
     ms = ctypes.c_float()
-    for e0, e1, pl in gen.blur_events:
+    for e0, e1, pl, low in gen.blur_events:
         _lib.check(lib.fsg_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "fsg_event_elapsed_ms")
         blur_total_ms += ms.value
         sections.append(pl)
+        lows.append(low)
     _drop_events(gen.blur_events)
     gen.blur_events = None
-    traffic_launch, nlaunch = blur_traffic(sections, args.size)
-    npass = sum(len(s) for s in sections)
-    us_launch = blur_total_ms * 1e3 / max(nlaunch, 1)
-    # bytes ONE blur launch must move: the volume read once and written once (8 B/voxel).  The fused y+z launch does two
-    # axis passes for those bytes (its intermediate stays in LDS): the pass-equivalent rate is reported separately.
-    bytes_launch = 8.0 * nvox
-    achieved = bytes_launch / us_launch / 1e3 if nlaunch else 0.0
-    # whole step: SURVEY 8(d) per-kernel algorithmic bytes with the fusions as built (gamma/bias in the warp epilogue: 0;
-    # K9+K10 one evaluation): K1 5 + warp 8 (image) + 5 (uint8 label read, float32 label write) + blur 24 + K7 (4 + 4mu) + K9 (4mu + 4) B/voxel
+    # What the events bracket.  r03 default: the FUSED pair (csrc/fsg_blur_rs.hip) -- blur and down-sampling of an axis as one
+    # operator: x launch reads N, writes N m0/n0; y,z launch reads N m0/n0, writes M (+ the noise draw).  Unfused
+    # (--tune 16384, or a configuration outside the fused domain): x pass + fused y,z pass, 8 B/voxel each.
     size_v = float(args.size)
-    mu = float(np.mean([(int(size_v * 0.5 / s[0]) / size_v) ** 3 for s in mus_seen if s])) if mus_seen else 1.0
-    step_bytes = (50.0 + 8.0 * mu) * nvox
+    fused = [bool(lib.fsg_blur_resample_supported(args.size, args.size, args.size, lo[0], lo[1], lo[2],
+                                                  *[2 * dict(sec).get(a_, 0) + 1 for a_ in range(3)])) for sec, lo in zip(sections, lows)]
+    alg_bytes, traffic_bytes, nlaunch, npass = 0.0, 0.0, 0, 0
+    rs_table = None
+    rs_files = sorted((REPO / "profiles").glob("r*_blur_rs_pmc.json"))
+    if rs_files:
+        rs_table = json.loads(rs_files[-1].read_text())["sizes"].get(str(args.size))
+
+    def rs_ratio(prefix, R):
+        if not rs_table:
+            return None
+        pts = {int(k[len(prefix):].split(",")[0].rstrip(">")): v["traffic_over_algorithmic"] for k, v in rs_table.items()
+               if k.startswith(prefix)}
+        return pts[min(pts, key=lambda r_: abs(r_ - R))] if pts else None
+
+    traffic_known = True
+    for sec, lo, fz in zip(sections, lows, fused):
+        npass += len(sec)
+        if fz:
+            bx = 4.0 * nvox + 4.0 * nvox * lo[0] / size_v
+            byz = 4.0 * nvox * lo[0] / size_v + 4.0 * lo[0] * lo[1] * lo[2]
+            alg_bytes += bx + byz
+            nlaunch += 2
+            R = dict(sec)
+            rx, ryz = rs_ratio("blur_rs_x_kernel<", R.get(0, 1)), rs_ratio("blur_rs_yz_kernel<", max(R.get(1, 1), R.get(2, 1)))
+            if rx is None or ryz is None:
+                traffic_known = False
+            else:
+                traffic_bytes += rx * bx + ryz * byz
+        else:
+            launches = _blur_launch_plan(sec)
+            alg_bytes += 8.0 * nvox * len(launches)
+            nlaunch += len(launches)
+            t_l, _n = blur_traffic([sec], args.size)
+            if t_l is None:
+                traffic_known = False
+            else:
+                traffic_bytes += t_l * len(launches)
+    us_launch = blur_total_ms * 1e3 / max(nlaunch, 1)
+    bytes_launch = alg_bytes / max(nlaunch, 1)
+    traffic_launch = traffic_bytes / max(nlaunch, 1) if (traffic_known and nlaunch) else None
+    achieved = bytes_launch / us_launch / 1e3 if nlaunch else 0.0
+    n_fused = sum(fused)
+    # whole step: SURVEY 8(d) per-kernel algorithmic bytes with the fusions as built (gamma/bias in the warp epilogue: 0; blur
+    # and down-sampling per axis; K9+K10 one evaluation): K1 5 + warp 8 (image) + 5 (uint8 label read, float32 label write)
+    # + x launch (4 + 4 mu_x) + y,z launch (4 mu_x + 4 mu) + K9 (4 mu + 4) B/voxel, mu_x = m/n, mu = M/N
+    mus_x = [int(size_v * 0.5 / s_[0]) / size_v for s_ in mus_seen if s_]
+    mu_x = float(np.mean(mus_x)) if mus_x else 1.0
+    mu = float(np.mean([v ** 3 for v in mus_x])) if mus_x else 1.0
+    step_bytes = (26.0 + 8.0 * mu_x + 8.0 * mu) * nvox
 
     result = {
         "metric": "synthetic volumes/sec at 256^3 (full deform+GMM+blur+resample path)",
@@ -610,20 +653,27 @@ def run(args, rank, world, local):
                    "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams,
                    **({"tuning_flags": args.tune} if args.tune else {})},
         "roofline": {"bound": "hbm",
-                     "kernel": "separable 3-pass blur = x pass (blur_strided_v4) + fused y,z pass (blur_yz_fused_kernel), "
-                               "HIP events on the launch stream around the blur launches of every 4th timed sample (rank 0)",
+                     "kernel": ("separable blur, fused per axis with the down-sampling (csrc/fsg_blur_rs.hip): x launch "
+                                "(blur_rs_x_kernel) + y,z launch with the noise epilogue (blur_rs_yz_kernel)"
+                                if n_fused == len(sections) and sections else
+                                "separable 3-pass blur = x pass (blur_strided_v4) + fused y,z pass (blur_yz_fused_kernel)")
+                               + "; HIP events on the launch stream around those launches of every 4th timed sample (rank 0)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": (None if traffic_launch is None else int(traffic_launch)),
                      "us_per_launch": round(us_launch, 2), "launches_timed": nlaunch,
                      "algorithmic_bytes_per_launch": int(bytes_launch),
-                     "accounting": "8 B/voxel per launch (volume read once + written once); the fused y+z launch covers two "
-                                   "axis passes with those bytes",
-                     "effective_pass_GBps": round(8.0 * nvox * npass / max(blur_total_ms * 1e3, 1e-9) / 1e3, 1),
+                     "accounting": "bytes one launch must move, averaged over the timed launches: fused x launch 4N + 4N m/n "
+                                   "(volume read once, x-resampled volume written once), fused y,z launch 4N m/n + 4M (M = "
+                                   "low-res voxels of that sample); unfused launches 8 B/voxel.  traffic = those bytes x the "
+                                   "traffic/algorithmic ratio of the launch's kernel in the committed PMC table "
+                                   "(profiles/r03_d_blur_rs_pmc.json: 1.00-1.03)",
+                     "samples_fused": n_fused, "samples_timed": len(sections),
                      "axis_passes_per_sample": round(npass / max(len(sections), 1), 2),
                      "launches_per_sample": round(nlaunch / max(len(sections), 1), 2)},
-        "roofline_step": {"bound": "hbm", "bytes_per_voxel": "50 + 8*mu (K1 5, warp 8 image + 1 uint8 label read + 4 float32 label write, blur 24, K7 4+4mu, K9/K10 4+4mu)",
-                          "mu_mean": round(mu, 4), "algorithmic_bytes_per_step": int(step_bytes),
+        "roofline_step": {"bound": "hbm", "bytes_per_voxel": "26 + 8*mu_x + 8*mu (K1 5, warp 8 image + 1 uint8 label read + 4 float32 label write, "
+                                                             "blur+resample x 4+4mu_x, y,z 4mu_x+4mu, K9/K10 4+4mu)",
+                          "mu_mean": round(mu, 4), "mu_x_mean": round(mu_x, 4), "algorithmic_bytes_per_step": int(step_bytes),
                           "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }

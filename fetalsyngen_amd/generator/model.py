@@ -139,7 +139,8 @@ class FetalSynthGen:
         self.device = device
         self.rng = rng  # None: module default (fetalsyngen_amd.rng.get_mode())
         self.native_pipeline = True  # one fsg_sample_run call per sample when the inputs allow it
-        self.blur_events = None      # set to a list to have HIP events recorded around each sample's blur passes
+        self.blur_events = None      # set to a list: (begin, end, [(axis, radius)], low-res shape) per sample, HIP events recorded
+                                     # around the blur (+ down-sampling, when fused) launches inside the native call
         self.blur_events_every = 1   # ... of every k-th sample only (an event record is a barrier packet: ~5.5 us of bubble)
         self._blur_tick = 0
         self.stage_traces = None     # set to a list: every fused sample appends a StageTrace (per-launch HIP events)
@@ -603,7 +604,8 @@ class FetalSynthGen:
         if events is not None:
             fbiv = self._flat["iv"]
             nt = [int(fbiv[self._I["BLUR_NTAPS"] + a_]) for a_ in range(3)]
-            self.blur_events.append((events[0], events[1], [(a_, nt[a_] // 2) for a_ in range(3) if nt[a_]]))
+            self.blur_events.append((events[0], events[1], [(a_, nt[a_] // 2) for a_ in range(3) if nt[a_]],
+                                     tuple(int(v) for v in c.rplan.new_size)))
         fb = self._flat
         rc = lib.fsg_sample_pack_run(fb["ivp"], self._I["COUNT"], fb["fvp"], 17, fb["tbp"], K._stream(dev))
         if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
@@ -636,7 +638,8 @@ class FetalSynthGen:
             lib = _lib.load()
             e0, e1 = lib.fsg_event_create(), lib.fsg_event_create()
             p.ev_blur_begin, p.ev_blur_end = e0, e1
-            self.blur_events.append((e0, e1, [(a_, int(p.blur_ntaps[a_]) // 2) for a_ in range(3) if p.blur_ntaps[a_]]))
+            self.blur_events.append((e0, e1, [(a_, int(p.blur_ntaps[a_]) // 2) for a_ in range(3) if p.blur_ntaps[a_]],
+                                     tuple(int(v) for v in p.low_shape)))
         rc = _lib.load().fsg_sample_run(C.byref(p), K._stream(dev))
         if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
             return None
@@ -1001,7 +1004,8 @@ class FetalSynthGen:
         rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, 82, C.byref(d), K._stream(dev))
         if events is not None:
             if rc == 0 and d.resample_active:
-                self.blur_events.append((events[0], events[1], [(a_, int(d.blur_ntaps[a_]) // 2) for a_ in range(3) if d.blur_ntaps[a_]]))
+                self.blur_events.append((events[0], events[1], [(a_, int(d.blur_ntaps[a_]) // 2) for a_ in range(3) if d.blur_ntaps[a_]],
+                                         tuple(int(v) for v in d.low_shape)))
             else:
                 kc.lib.fsg_event_destroy(events[0])
                 kc.lib.fsg_event_destroy(events[1])
