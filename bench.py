@@ -590,12 +590,12 @@ def run(args, rank, world, local):
     if rs_files:
         rs_table = json.loads(rs_files[-1].read_text())["sizes"].get(str(args.size))
 
-    def rs_ratio(prefix, R):
+    def rs_ratio(prefix, radius):
         if not rs_table:
             return None
         pts = {int(k[len(prefix):].split(",")[0].rstrip(">")): v["traffic_over_algorithmic"] for k, v in rs_table.items()
                if k.startswith(prefix)}
-        return pts[min(pts, key=lambda r_: abs(r_ - R))] if pts else None
+        return pts[min(pts, key=lambda r_: abs(r_ - radius))] if pts else None
 
     traffic_known = True
     for sec, lo, fz in zip(sections, lows, fused):
@@ -605,8 +605,9 @@ def run(args, rank, world, local):
             byz = 4.0 * nvox * lo[0] / size_v + 4.0 * lo[0] * lo[1] * lo[2]
             alg_bytes += bx + byz
             nlaunch += 2
-            R = dict(sec)
-            rx, ryz = rs_ratio("blur_rs_x_kernel<", R.get(0, 1)), rs_ratio("blur_rs_yz_kernel<", max(R.get(1, 1), R.get(2, 1)))
+            radii = dict(sec)
+            rx = rs_ratio("blur_rs_x_kernel<", radii.get(0, 1))
+            ryz = rs_ratio("blur_rs_yz_kernel<", max(radii.get(1, 1), radii.get(2, 1)))
             if rx is None or ryz is None:
                 traffic_known = False
             else:

@@ -170,7 +170,15 @@ __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict
 }
 
 // ---- axes 1 + 2 ----------------------------------------------------------------------------------------------------------
-constexpr int RSY_TL = 8, RSY_IN = 4 * RSY_TL, RSY_WROWS = RSY_TL + 1;  // input y rows per wave / workgroup; output rows a wave can emit (m <= n, + an "outside" one)
+// rows per wave / waves per workgroup: 8 / 4 measured best at 256^3 (4 / 4: latency chains too short a work item, 44 -> 28 us
+// at m = 250 without noise going to 8 / 4; 16 / 2: 197-254 VGPRs, 31 -> 41 us at m = 171)
+#ifndef FSG_RSY_TL
+#define FSG_RSY_TL 8
+#endif
+#ifndef FSG_RSY_NW
+#define FSG_RSY_NW 4
+#endif
+constexpr int RSY_TL = FSG_RSY_TL, RSY_NW = FSG_RSY_NW, RSY_IN = RSY_NW * RSY_TL, RSY_WROWS = RSY_TL + 1;  // input y rows per wave / workgroup; output rows a wave can emit (m <= n, + an "outside" one)
 
 struct NoiseK {
   int mode;  // 0 none, 1 pointer, 2 Philox
@@ -179,7 +187,7 @@ struct NoiseK {
   float std;
 };
 
-// Four INDEPENDENT waves per workgroup, no barrier: wave w owns the input rows yin0 + 8w .. + 7 of its x-plane and everything
+// RSY_NW INDEPENDENT waves per workgroup, no barrier: wave w owns RSY_TL input rows of its x-plane (yin0 + 8w .. + 7) and everything
 // downstream of them -- the output rows whose lower neighbour they are, their z blur (in place in the wave's own LDS rows)
 // and their z resampling + noise.  Versions with workgroup-wide phases (y for the tile, barrier, z blur for the tile,
 // barrier, lerp for the tile) and with 4 rows per wave ran 2-3x slower: every phase is short and ends in a wait, so a wave
@@ -188,7 +196,7 @@ struct NoiseK {
 // SAME: both axes use one tap set (the isotropic case the generator draws): Kz is not read, which halves the kernel's scalar
 // register footprint (two tap sets spill 40-77 SGPRs at R >= 4).
 template <int R, bool SAME, int NQ>
-__global__ __launch_bounds__(256) void blur_rs_yz_kernel(const float4* __restrict__ src, float* __restrict__ dst, int ny, int nz,
+__global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* __restrict__ src, float* __restrict__ dst, int ny, int nz,
                                                          int m1, int m2, const fsg_tap* __restrict__ taby,
                                                          const fsg_tap* __restrict__ tabz, TapsK Ky, TapsK Kz, NoiseK NZ) {
   constexpr int RP = (R + 3) & ~3, TL = RSY_TL, NB = TL + 1;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void blur_rs_yz_kernel(const float4* __restric
 size_t rs_yz_lds(int nz, int m2, int R) {
   const int RP = (R + 3) & ~3;
   (void)m2;
-  return ((size_t)4 * RSY_WROWS * (nz + 2 * RP)) * sizeof(float);
+  return ((size_t)RSY_NW * RSY_WROWS * (nz + 2 * RP)) * sizeof(float);
 }
 
 template <int R>
@@ -388,7 +396,7 @@ int launch_rs_yz(const float* src, float* dst, int m0, int ny, int nz, int m1, i
   bool same = true;
   for (int t = 0; t < RS_KCAP + 3; ++t) same = same && Ky.w[t] == Kz.w[t];
 #define RS_YZ(S, Q)                                                                                            \
-  hipLaunchKernelGGL((blur_rs_yz_kernel<R, S, Q>), dim3(tiles_y * (unsigned)m0), dim3(64, 4), lds, st,             \
+  hipLaunchKernelGGL((blur_rs_yz_kernel<R, S, Q>), dim3(tiles_y * (unsigned)m0), dim3(64, RSY_NW), lds, st,        \
                      reinterpret_cast<const float4*>(src), dst, ny, nz, m1, m2, ty, tz, Ky, S ? Ky : Kz, NZ)
   if (m2 <= 256) { if (same) RS_YZ(true, 1); else RS_YZ(false, 1); }
   else           { if (same) RS_YZ(true, 2); else RS_YZ(false, 2); }
