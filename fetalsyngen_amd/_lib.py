@@ -103,6 +103,8 @@ class SamplePlan(C.Structure):
         ("trace_events", C.c_void_p),
         ("trace_ids", C.c_void_p),
         ("trace_cap", C.c_int32),
+        ("trace_start", C.c_int32),
+        ("trace_first_id", C.c_int32),
     ]
 
 

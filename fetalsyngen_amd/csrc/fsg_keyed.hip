@@ -448,6 +448,14 @@ int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws*
   q.ev_blur_begin = (void*)(uintptr_t)iv[FSG_KEYED_I_EV_BLUR_BEGIN];
   q.ev_blur_end = (void*)(uintptr_t)iv[FSG_KEYED_I_EV_BLUR_END];
 
+  if (q.trace_events && q.trace_ids && q.trace_cap > 1) {  // stage trace: an event before the draw kernel, the next one behind it
+    hipError_t e = hipEventRecord((hipEvent_t)q.trace_events[0], fsg_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    q.trace_ids[0] = FSG_ST_BEGIN;
+    q.trace_ids[q.trace_cap] = 1;
+    q.trace_start = 1;
+    q.trace_first_id = FSG_ST_DRAW;
+  }
   rc = launch_draw(*K, d, base, stream);
   if (rc) return rc;
   return fsg_sample_run(&q, stream);

@@ -93,7 +93,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 
   // stage trace (measurement only): an event behind every launch, see fsg_sample_plan::trace_events
-  int ntrace = 0;
+  int ntrace = p->trace_start > 0 ? p->trace_start : 0;
   auto mark = [&](int id) -> int {
     if (!p->trace_events || !p->trace_ids || ntrace >= p->trace_cap) return 0;
     hipError_t e = hipEventRecord((hipEvent_t)p->trace_events[ntrace], st);
@@ -102,7 +102,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     p->trace_ids[p->trace_cap] = ntrace;
     return 0;
   };
-  FSG_TRY(mark(FSG_ST_BEGIN));
+  FSG_TRY(mark(p->trace_start > 0 ? p->trace_first_id : FSG_ST_BEGIN));
 
   const bool has_gamma = p->epi.gamma > 0.f, has_bias = p->epi.bias != nullptr;
   bool head_done = false;

@@ -457,6 +457,9 @@ typedef struct fsg_sample_plan {
   void** trace_events;
   int32_t* trace_ids;
   int32_t trace_cap;
+  int32_t trace_start;           /* events the caller has already recorded (fsg_keyed_sample_run: 1, the one before its draw
+                                  * kernel); the first event of this call then carries trace_first_id instead of FSG_ST_BEGIN */
+  int32_t trace_first_id;
 } fsg_sample_plan;
 enum {
   FSG_ST_BEGIN = 0, FSG_ST_UPLOAD = 1, FSG_ST_DRAW = 2, FSG_ST_HEAD = 3, FSG_ST_FLOORMIN = 4, FSG_ST_WARP = 5, FSG_ST_BLUR_X = 6,
