@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6
 # the real reference timed in the build container: the anchor the CPU port is read against
 REFERENCE_ANCHOR = {"value": 0.156, "unit": "volumes/s", "threads": 8, "s_per_volume": 6.42,
                     "what": "real reference (imported, CPU, torch 2.10, all gates on, sub-sta21 256^3) in the build "
-                            "container, BASELINE.md section 2; the port below vectorises the reference's Python loops "
-                            "and is therefore FASTER than the reference"}
+                            "container, BASELINE.md section 2.  On that machine (8 threads) the port takes 4.7-6.8 s per volume, "
+                            "i.e. the reference's cost within ~25 %; the figure below is the port on THIS box's host cores"}
 
 
 def parse_args(argv=None):
@@ -346,6 +346,7 @@ def cpu_baseline(shape, threads):
     from oracle import fsg_oracle as O
 
     torch.set_num_threads(threads)
+    O.REFERENCE_LOOPS = True  # the zooms as the reference's per-slice Python loops (utils/generation.py:374-386), same values
     seg, seeds = make_seed_volumes(shape)
     cfg = O.Config(shape, prob=1.0)
     seg_t = torch.from_numpy(seg)
@@ -358,8 +359,8 @@ def cpu_baseline(shape, threads):
         times.append(time.perf_counter() - t0)
     timed = times[1:]
     return {"value": round(len(timed) / sum(timed), 4), "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"1 warm-up + {len(timed)} timed {shape[0]}^3 volumes, all gates on, torch CPU ops "
-                      f"({sum(timed):.2f} s, {min(timed):.2f}-{max(timed):.2f} s per volume)",
+            "sample": f"1 warm-up + {len(timed)} timed {shape[0]}^3 volumes, all gates on, torch CPU ops, zooms in the reference's "
+                      f"per-slice loop form ({sum(timed):.2f} s, {min(timed):.2f}-{max(timed):.2f} s per volume)",
             "reference_anchor": REFERENCE_ANCHOR}
 
 

@@ -219,3 +219,23 @@ def test_sublattice_option_equals_the_full_evaluation():
     assert tuple(fm[:3]) == (0, 0, 0) and tuple(sm[:3]) == (0, 0, 0)
     ix = np.ix_(*index)
     assert torch.equal(si, fi[ix]) and torch.equal(sj, fj[ix]) and torch.equal(sk, fk[ix])
+
+
+def test_reference_loop_form_of_the_zoom_equals_the_vectorised_form():
+    """`REFERENCE_LOOPS` (what bench.py's cpu_baseline times: the reference's per-slice loops, utils/generation.py:374-386)
+    changes the cost structure of the oracle's zoom, not one value."""
+    import numpy as np
+    import torch
+
+    from oracle import fsg_oracle as O
+
+    rs = np.random.RandomState(3)
+    for shape, f in (((7, 5, 6), (2.3, 1.9, 3.4)), ((9, 8, 7, 3), (1.5, 2.0, 2.5)), ((12, 10, 8), (0.6, 0.75, 0.5))):
+        x = torch.from_numpy(rs.rand(*shape).astype(np.float32))
+        a = O.linear_zoom(x, np.array(f))
+        O.REFERENCE_LOOPS = True
+        try:
+            b = O.linear_zoom(x, np.array(f))
+        finally:
+            O.REFERENCE_LOOPS = False
+        assert torch.equal(a, b)
