@@ -332,8 +332,46 @@ def config4_sr(device, size=384, reps=3):
         torch.cuda.synchronize()
         ms.append(round((time.perf_counter() - t0) * 1e3, 1))
         stacks.append(int(meta["nstacks"]))
-    return {"workload": f"SimulateMotion on one {size}^3 volume (2-6 stacks of slices, PSF acquisition + reconstruction)",
-            "ms_per_volume": ms[1:], "nstacks": stacks[1:], "mean_ms": round(float(np.mean(ms[1:])), 1)}
+    out = {"workload": f"SimulateMotion on one {size}^3 volume (2-6 stacks of slices, PSF acquisition + reconstruction)",
+           "ms_per_volume": ms[1:], "nstacks": stacks[1:], "mean_ms": round(float(np.mean(ms[1:])), 1)}
+    # the two kernels that carry the stage (forward 37 %, adjoint 49 % of its GPU time), one stack of 80 slices at 0.8 mm in
+    # plane / 3 mm thick: HIP-event time, pixel-taps/s (their unit of work: one PSF tap of one slice pixel = a 2x2x2 gather +
+    # blend, or one scattered contribution) and the bytes they must move (the volume once + the slices once)
+    from fetalsyngen_amd import kernels as K
+    from fetalsyngen_amd.generator.artifacts.svort import get_PSF, random_stack
+
+    res, res_slice, thick, nsl = 0.5, 0.8, 3.0, 80
+    ss = int(np.ceil(int(np.sqrt(3 * size ** 2 / 2.0) * res / res_slice) / 32.0) * 32)
+    psf = get_PSF(res_ratio=(res_slice / res, res_slice / res, thick / res)).to(device)
+    np.random.seed(0)
+    tr = random_stack(nsl, gap=size * res / nsl / res, max_angle=0.3).to(device)
+    vol = torch.rand(shape, device=device)
+    rs_ = res_slice / res
+    sl = K.slice_acq_forward(tr, vol, None, None, psf, (ss, ss), rs_)
+    ntap, npix = int((psf > 0).sum()), nsl * ss * ss
+
+    def timed(fn, reps_=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps_):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps_
+
+    fwd = timed(lambda: K.slice_acq_forward(tr, vol, None, None, psf, (ss, ss), rs_))
+    adj = timed(lambda: K.slice_acq_adjoint(tr, psf, sl, None, None, shape, rs_, interp_psf=True, equalize=True))
+    byt = 4.0 * size ** 3 + 4.0 * npix
+    out["kernels"] = {
+        "problem": {"slices": [nsl, ss, ss], "psf": list(psf.shape), "psf_taps": ntap, "pixel_taps": npix * ntap},
+        "forward": {"kernel": "sa_forward_linear_fast_kernel", "ms": round(fwd, 3), "G_pixel_taps_per_s": round(npix * ntap / fwd / 1e6, 1),
+                    "algorithmic_bytes": int(byt), "GBps": round(byt / fwd / 1e6, 1), "bound": "L1/TA gather rate (4 wave-gathers per tap), not HBM"},
+        "adjoint": {"kernel": "sa_adjoint_nn_lds_kernel (+ equalize)", "ms": round(adj, 3), "G_pixel_taps_per_s": round(npix * ntap / adj / 1e6, 1),
+                    "algorithmic_bytes": int(byt + 4.0 * size ** 3), "GBps": round((byt + 4.0 * size ** 3) / adj / 1e6, 1),
+                    "bound": "two passes over the taps in LDS (ds_add pre-summation) + one global atomic per touched cell"}}
+    return out
 
 
 def cpu_baseline(shape, threads):
@@ -568,6 +606,30 @@ def run(args, rank, world, local):
     roofline_kernels = stage_rooflines(traces, nvox)
     for tr in traces:
         tr.close()
+    # what one event record costs the launch stream by itself (a barrier packet): 33 back-to-back records, median gap.
+    # `us_net` = `us` minus that bubble; the net figures add up to the un-instrumented step (cross-check below).
+    from fetalsyngen_amd import kernels as _K
+    evs = [_lib.load().fsg_event_create() for _ in range(33)]
+    st_raw = _K._stream(torch.device(device))
+    torch.cuda.synchronize()
+    for e in evs:
+        _lib.load().fsg_event_record(e, st_raw)
+    torch.cuda.synchronize()
+    gaps, ms_ = [], ctypes.c_float()
+    for e0, e1 in zip(evs, evs[1:]):
+        _lib.check(_lib.load().fsg_event_elapsed_ms(e0, e1, ctypes.byref(ms_)), "fsg_event_elapsed_ms")
+        gaps.append(ms_.value * 1e3)
+    for e in evs:
+        _lib.load().fsg_event_destroy(e)
+    bubble = float(np.median(gaps))
+    net = 0.0
+    for k_, v_ in roofline_kernels.items():
+        if isinstance(v_, dict):
+            v_["us_net"] = round(max(v_["us"] - bubble, 0.0), 2)
+            v_["frac_net"] = (round(v_["algorithmic_bytes"] / v_["us_net"] / 1e3 / HBM_PEAK_GBS, 4) if v_["us_net"] > 0 else None)
+            net += v_["us_net"] * v_["launches_per_sample"]
+    roofline_kernels["_event_bubble_us"] = round(bubble, 2)
+    roofline_kernels["_sum_us_net_per_sample"] = round(net, 2)
 
     lib = _lib.load()
     blur_total_ms, sections, lows = 0.0, [], []
@@ -679,6 +741,7 @@ def run(args, rank, world, local):
                           "achieved": round(step_bytes / (dt / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    roofline_kernels["_check_sum_net_le_step"] = bool(roofline_kernels["_sum_us_net_per_sample"] <= dt / args.steps * 1e6 * 1.03)
     result["roofline_kernels"] = roofline_kernels
     result.update(result_extra)
 

@@ -230,6 +230,7 @@ SIGNATURES = {
     "fsg_keyed_sample_run": [P, P, I, P, P],
     "fsg_keyed_fill_block": [P, C.POINTER(KeyedDraws), P, P],
     "fsg_event_destroy": [P],
+    "fsg_event_record": [P, P],
     "fsg_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
 }
 SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32]),

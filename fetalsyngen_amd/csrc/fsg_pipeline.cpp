@@ -427,6 +427,9 @@ extern "C" void* fsg_event_create(void) {
   hipEvent_t e = nullptr;
   return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
 }
+extern "C" int fsg_event_record(void* e, void* stream) {
+  return e ? (int)hipEventRecord((hipEvent_t)e, (hipStream_t)stream) : FSG_E_BADARG;
+}
 extern "C" int fsg_event_destroy(void* e) { return e ? (int)hipEventDestroy((hipEvent_t)e) : FSG_E_BADARG; }
 extern "C" int fsg_event_elapsed_ms(void* begin, void* end, float* ms) {
   if (!begin || !end || !ms) return FSG_E_BADARG;

@@ -609,6 +609,7 @@ int fsg_cast_f32_to_f16(const float* x, size_t n, void* out_f16, void* stream);
 
 /* hipEvent helpers for ctypes callers (timing on the launch stream). elapsed_ms synchronises on `end`. */
 void* fsg_event_create(void);
+int fsg_event_record(void* event, void* stream);
 int fsg_event_destroy(void* event);
 int fsg_event_elapsed_ms(void* begin, void* end, float* ms);
 
