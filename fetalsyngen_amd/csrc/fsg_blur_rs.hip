@@ -104,6 +104,16 @@ __device__ __forceinline__ float rs_rl(float v, int q) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), q));
 }
 
+// A row of the blur's input through a raw buffer descriptor: a row outside the axis (negative offset -> wraps past the
+// descriptor's size, or beyond its end) comes back as zeros from the range check -- the blur's zero padding without a clamped
+// address and four selects per row (descriptor sizes < 2^31 bytes: fsg_blur_resample_supported).
+// (the builtin's result is cast as a whole: element access on it directly compiles to a ONE-dword load, hipcc 7.2)
+typedef float rs_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rs_row_load(__amdgpu_buffer_rsrc_t r, unsigned byte_offset) {
+  const rs_f4 v = __builtin_bit_cast(rs_f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---- axis 0 ------------------------------------------------------------------------------------------------------------
 constexpr int RSX_TL = 16;
 
@@ -111,12 +121,13 @@ template <int R>
 __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n, int m,
                                                         int inner4, const fsg_tap* __restrict__ tab, TapsK K) {
   constexpr int TL = RSX_TL, NB = TL + 1;  // NB blurred rows l0 .. l0 + TL: the last one only ever serves as an upper neighbour
-  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);  // (a wave = one row of the block: uniform, and the compiler should know)
   const int c = blockIdx.x * 64 + tx;
   const int l0 = (blockIdx.y * 4 + ty) * TL;
   if (l0 >= n) return;  // whole wave
   const bool live = c < inner4;
-  const float4* s = src + (live ? c : 0);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)n * (unsigned)inner4 * 16u, 0x00020000);
+  const unsigned colb = (unsigned)(live ? c : 0) * 16u, rowb = (unsigned)inner4 * 16u;
   const float fr = (float)m / (float)n;
   const int jg = rs_chunk_guess(m, l0, fr);
   const LaneTaps lt0 = rs_lane_taps(tab, m, jg);  // requested now, looked at after the blur
@@ -126,11 +137,9 @@ __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict
 #pragma unroll
   for (int t = 0; t < NB + 2 * R; ++t) {
     const int l = l0 + t - R;
-    // unconditional load of a clamped row, zeroed afterwards when outside the axis (zero padding): a predicated load hides
-    // the number of loads in flight from the compiler, which then waits for all of them before every use
-    float4 v = s[(size_t)min(max(l, 0), n - 1) * inner4];
-    const bool in = l >= 0 && l < n;
-    v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+    // unconditional load (a predicated one hides the number of loads in flight from the compiler, which then waits for all
+    // of them before every use); rows outside the axis read as zeros (rs_row_load)
+    const float4 v = rs_row_load(rsrc, (unsigned)l * rowb + colb);
 #pragma unroll
     for (int o = 0; o < NB; ++o) {
       const int tap = t - o;
@@ -178,6 +187,10 @@ __global__ __launch_bounds__(256) void blur_rs_x_kernel(const float4* __restrict
 #ifndef FSG_RSY_NW
 #define FSG_RSY_NW 4
 #endif
+#ifndef FSG_RSY_BATCH
+#define FSG_RSY_BATCH 4
+#endif
+constexpr int RSY_BATCH = FSG_RSY_BATCH;
 constexpr int RSY_TL = FSG_RSY_TL, RSY_NW = FSG_RSY_NW, RSY_IN = RSY_NW * RSY_TL, RSY_WROWS = RSY_TL + 1;  // input y rows per wave / workgroup; output rows a wave can emit (m <= n, + an "outside" one)
 
 struct NoiseK {
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* _
   constexpr int RP = (R + 3) & ~3, TL = RSY_TL, NB = TL + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int inner4 = nz >> 2, pitch = nz + 2 * RP;
-  const int tx = threadIdx.x, tyc = threadIdx.y;
+  const int tx = threadIdx.x, tyc = __builtin_amdgcn_readfirstlane((int)threadIdx.y);  // wave-uniform: row offsets become scalar
   float* rows = lds + (size_t)tyc * RSY_WROWS * pitch;            // this wave's rows, zero z halos
   const int tiles_y = (ny + RSY_IN - 1) / RSY_IN;
   const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* _
   const size_t plane4 = (size_t)bx * ny * inner4;
   const int l0 = yin0 + tyc * TL;
   if (l0 >= ny) return;  // whole wave; there is no barrier in this kernel
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + plane4), 0, (unsigned)ny * (unsigned)nz * 4u, 0x00020000);
   // requested now, looked at later: the y taps of the chunk's outputs, the z taps of this lane's outputs
   const int jg = rs_chunk_guess(m1, l0, (float)m1 / (float)ny);
   const LaneTaps lt0 = rs_lane_taps(taby, m1, jg);
@@ -239,28 +253,43 @@ __global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* _
   for (int cb = 0; cb < inner4; cb += 64) {
     const bool live = cb + tx < inner4;
     const int c = min(cb + tx, inner4 - 1);
-    const float4* s = src + plane4 + c;
+    const unsigned colb = (unsigned)c * 16u, rowb = (unsigned)inner4 * 16u;
     float4 acc[NB];
 #pragma unroll
     for (int o = 0; o < NB; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The NT row loads go out in batches of RSY_BATCH, two batches ahead of the arithmetic, with a scheduling barrier between
+    // the batches: left to itself the scheduler hoists all NT loads (and their NT uniform 64-bit row offsets) to the top --
+    // 4 NT vector + 2 NT scalar registers live at once, which is what set this kernel's occupancy (141-244 VGPRs, 16-130
+    // spilled SGPRs at R >= 3).  Same loads, same arithmetic in the same order.
+    constexpr int NT = NB + 2 * R;
+    float4 rowv[NT];
+    int l0s = l0;  // (opaque copy: the row offsets are computed next to their loads instead of NT scalar pairs ahead of the loop)
+    asm volatile("" : "+s"(l0s));
 #pragma unroll
-    for (int t = 0; t < NB + 2 * R; ++t) {
-      const int l = l0 + t - R;
-      float4 v = s[(size_t)min(max(l, 0), ny - 1) * inner4];  // unconditional, zeroed when outside (see blur_rs_x_kernel)
-      const bool in = l >= 0 && l < ny;
-      v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+    for (int t = 0; t < NT && t < 2 * RSY_BATCH; ++t) rowv[t] = rs_row_load(rsrc, (unsigned)(l0s + t - R) * rowb + colb);
 #pragma unroll
-      for (int o = 0; o < NB; ++o) {
-        const int tap = t - o;
-        if (tap >= 0 && tap <= 2 * R) {
-          const float w = Ky.w[tap];
-          acc[o].x = fmaf(w, v.x, acc[o].x);
-          acc[o].y = fmaf(w, v.y, acc[o].y);
-          acc[o].z = fmaf(w, v.z, acc[o].z);
-          acc[o].w = fmaf(w, v.w, acc[o].w);
+    for (int b0 = 0; b0 < NT; b0 += RSY_BATCH) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = b0 + 2 * RSY_BATCH; t < NT && t < b0 + 3 * RSY_BATCH; ++t)
+        rowv[t] = rs_row_load(rsrc, (unsigned)(l0s + t - R) * rowb + colb);  // unconditional; zeros outside the axis
+#pragma unroll
+      for (int t = b0; t < NT && t < b0 + RSY_BATCH; ++t) {
+        const float4 v = rowv[t];
+#pragma unroll
+        for (int o = 0; o < NB; ++o) {
+          const int tap = t - o;
+          if (tap >= 0 && tap <= 2 * R) {
+            const float w = Ky.w[tap];
+            acc[o].x = fmaf(w, v.x, acc[o].x);
+            acc[o].y = fmaf(w, v.y, acc[o].y);
+            acc[o].z = fmaf(w, v.z, acc[o].z);
+            acc[o].w = fmaf(w, v.w, acc[o].w);
+          }
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     const ChunkTaps ct = rs_chunk_resolve(taby, m1, l0, l0 + TL, jg, lt0);
     const LaneTaps lt = ct.t;
     const int jl0 = ct.jb - ct.shift;                 // output of lane 0 of the taps
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* _
           // outputs e0 .. e0 + 3 = elements sh .. 3 of block e0 >> 2 and 0 .. sh - 1 of the next one
           // (the next block is the NEXT LANE's own block -- its outputs start four elements further -- so it comes over by a
           // lane shift instead of a second Philox + Box-Muller evaluation; only the last lane of the row may need its own)
-          const float4 za = fsg_randn4(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2));
+          const float4 za = fsg_randn4<true>(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2));
           float z[4] = {za.x, za.y, za.z, za.w};
           if (sh) {
             float4 zb = make_float4(__shfl_down(za.x, 1, FSG_WAVE), __shfl_down(za.y, 1, FSG_WAVE), __shfl_down(za.z, 1, FSG_WAVE),
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(64 * RSY_NW) void blur_rs_yz_kernel(const float4* _
             // lane 63's successor is not in this wave-instruction: needed only if one of its VALID outputs reaches into it
             const int nvalid63 = min(m2 - (63 + 64 * i) * 4, 4);  // uniform
             if (sh + nvalid63 - 1 >= 4) {
-              if (tx == 63) zb = fsg_randn4(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2) + 1);
+              if (tx == 63) zb = fsg_randn4<true>(NZ.seed, NZ.stream_id, (uint64_t)(e0 >> 2) + 1);
             }
             const float zz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
             if (sh == 1) { z[0] = zz[1]; z[1] = zz[2]; z[2] = zz[3]; z[3] = zz[4]; }
@@ -433,7 +462,7 @@ int fsg_blur_resample_supported(int n0, int n1, int n2, int m0, int m1, int m2, 
   for (int nt : {ntaps_x, ntaps_y, ntaps_z})
     if (nt < 3 || (nt & 1) == 0 || nt > RS_KCAP) return 0;
   if ((n2 & 3) || n2 > 512 || ((long long)n1 * n2 & 3)) return 0;
-  if ((size_t)n0 * n1 * n2 > (size_t)0x7FFFFFFF) return 0;
+  if ((size_t)n0 * n1 * n2 > ((size_t)1 << 29)) return 0;  // rows are addressed by 32-bit byte offsets in a buffer descriptor < 2^31 bytes
   const int Ryz = (ntaps_y > ntaps_z ? ntaps_y : ntaps_z) >> 1;
   if (rs_yz_lds(n2, m2, Ryz) > 64000) return 0;
   return 1;
@@ -450,7 +479,7 @@ int fsg_blur_resample_x_f32(const float* src, int n0, int n1, int n2, const fsg_
   if (rc) return rc;
   const long long inner = (long long)n1 * n2;
   if ((inner & 3) || ((((uintptr_t)src) | ((uintptr_t)dst)) & 15)) return FSG_E_ALIGN;
-  if ((size_t)n0 * inner > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  if ((size_t)n0 * inner > ((size_t)1 << 29)) return FSG_E_TOOBIG;  // 32-bit byte offsets in a descriptor < 2^31 bytes
   const int inner4 = (int)(inner >> 2);
   hipStream_t st = fsg_stream(stream);
   switch (R) {
@@ -482,6 +511,7 @@ int fsg_blur_resample_yz_noise_f32(const float* src, int m0, int n1, int n2, con
   if (rc) return rc;
   if ((n2 & 3) || n2 > 512 || (((uintptr_t)src) & 15)) return FSG_E_ALIGN;
   if ((size_t)m0 * n1 * n2 > (size_t)0x7FFFFFFF || (size_t)m0 * m1 * m2 > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
+  if ((size_t)n1 * n2 > ((size_t)1 << 29)) return FSG_E_TOOBIG;  // a plane is one buffer descriptor (< 2^31 bytes)
   NoiseK NZ{noise_mode, noise, seed, stream_id, noise_std};
   hipStream_t st = fsg_stream(stream);
   switch (R) {

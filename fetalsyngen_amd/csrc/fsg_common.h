@@ -78,10 +78,16 @@ __device__ __forceinline__ uint4 fsg_philox4x32_10(uint32_t c0, uint32_t c1, uin
   return make_uint4(c0, c1, c2, c3);
 }
 
-// four standard normals for counter block `blk`
+// four standard normals for counter block `blk`.  UNIFORM_KEY: the seed is wave-uniform (a kernel argument) and the call sits
+// in a loop -- the two key words pass through an empty asm so that the ten round keys are ten scalar adds per call instead of
+// twenty loop-invariant scalar registers (which the register allocator spilled to vector lanes: 8 v_readlane + 11 s_nop per
+// GMM group, 16-130 spilled registers in the blur + resample kernels).
+template <bool UNIFORM_KEY = false>
 __device__ __forceinline__ float4 fsg_randn4(uint64_t seed, uint64_t stream_id, uint64_t blk) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  if (UNIFORM_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
   uint4 r = fsg_philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)stream_id,
-                              (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+                              (uint32_t)(stream_id >> 32), k0, k1);
   const float S = 5.9604644775390625e-08f;  // 2^-24
   float u0 = (float)((r.x >> 8) + 1u) * S;  // (0, 1]
   float u1 = (float)((r.z >> 8) + 1u) * S;
@@ -115,6 +121,29 @@ __device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, 
                                                 uint64_t seed, uint64_t stream_id, float* __restrict__ out, unsigned blk,
                                                 unsigned nblk) {
   const size_t ngrp = (n + 3) >> 2;
+  if (!noise && (n & 3) == 0 && n <= ((size_t)1 << 30)) {
+    // The usual case on a lean path (r03): whole groups only, 32-bit offsets against uniform bases (one address register per
+    // access instead of a 64-bit add per pointer), no tail or injected-noise branches inside the loop.  Same values.
+    const uint8_t *q1 = l1 ? l1 : l0, *q2 = l2 ? l2 : l0, *q3 = l3 ? l3 : l0;
+    const uint32_t k1 = l1 ? 0xFFFFFFFFu : 0u, k2 = l2 ? 0xFFFFFFFFu : 0u, k3 = l3 ? 0xFFFFFFFFu : 0u;
+    const uint32_t ng = (uint32_t)ngrp, step = nblk * blockDim.x;
+    for (uint32_t g = blk * blockDim.x + threadIdx.x; g < ng; g += step) {
+      const uint32_t e = g << 2;
+      const uint32_t w0 = *reinterpret_cast<const uint32_t*>(l0 + e), w1 = *reinterpret_cast<const uint32_t*>(q1 + e);
+      const uint32_t w2 = *reinterpret_cast<const uint32_t*>(q2 + e), w3 = *reinterpret_cast<const uint32_t*>(q3 + e);
+      const uint32_t w = w0 + (w1 & k1) + (w2 & k2) + (w3 & k3);
+      const float4 r = fsg_randn4<true>(seed, stream_id, (uint64_t)g);
+      const float z[4] = {r.x, r.y, r.z, r.w};
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int l = (int)((w >> (8 * q)) & 255u);
+        v[q] = fmaxf(s_mu[l] + s_sg[l] * z[q], 0.f);  // (no NaN, and no -0: mu >= +0)
+      }
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (size_t)(e << 2)) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
   // The four label words of a group are requested TOGETHER: with `if (l1) w += *l1` the compiler put each load, its wait and
   // its add into a branch of their own -- four dependent round trips to memory per group, and the kernel ran at that latency
   // (36 us) whatever the arithmetic did; the same draw with the loads issued back to back is memory bound at 21 us
@@ -142,7 +171,7 @@ __device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) z[q] = (e + q < n) ? noise[e + q] : 0.f;
     } else {
-      const float4 r = fsg_randn4(seed, stream_id, (uint64_t)g);
+      const float4 r = fsg_randn4<true>(seed, stream_id, (uint64_t)g);
       z[0] = r.x; z[1] = r.y; z[2] = r.z; z[3] = r.w;
     }
     float v[4];
