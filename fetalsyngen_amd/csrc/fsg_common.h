@@ -127,6 +127,8 @@ __device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, 
     const uint8_t *q1 = l1 ? l1 : l0, *q2 = l2 ? l2 : l0, *q3 = l3 ? l3 : l0;
     const uint32_t k1 = l1 ? 0xFFFFFFFFu : 0u, k2 = l2 ? 0xFFFFFFFFu : 0u, k3 = l3 ? 0xFFFFFFFFu : 0u;
     const uint32_t ng = (uint32_t)ngrp, step = nblk * blockDim.x;
+    // (two groups per trip with their eight label words in flight together measured the same: the kernel runs at the cold-HBM
+    // rate of its 8 B/voxel, profiles/r03_g_notes.txt)
     for (uint32_t g = blk * blockDim.x + threadIdx.x; g < ng; g += step) {
       const uint32_t e = g << 2;
       const uint32_t w0 = *reinterpret_cast<const uint32_t*>(l0 + e), w1 = *reinterpret_cast<const uint32_t*>(q1 + e);
@@ -140,7 +142,7 @@ __device__ __forceinline__ void fsg_gmm_x4_loop(const uint8_t* __restrict__ l0, 
         const int l = (int)((w >> (8 * q)) & 255u);
         v[q] = fmaxf(s_mu[l] + s_sg[l] * z[q], 0.f);  // (no NaN, and no -0: mu >= +0)
       }
-      *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (size_t)(e << 2)) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (size_t)(g << 4)) = make_float4(v[0], v[1], v[2], v[3]);
     }
     return;
   }

@@ -581,8 +581,9 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   // domain (checked by the launcher): sz <= 256 and dz <= 256 -- a lane owns source elements lane + 64 c (c < 4) in the
   // y stage and outputs 4 lane .. 4 lane + 3 in the z stage, everything unrolled
   extern __shared__ __attribute__((aligned(16))) float zt_smem[];
-  float* yr = zt_smem;              // [4 waves][sz] y-blended row of each wave
-  float* xs = yr + 4 * Z.sz;        // [window rows][sz] x-blended source rows
+  float* yr = zt_smem;              // [4 waves][256] y-blended row of each wave (padded to the domain's 256: the y stage writes
+                                    // all four of a lane's columns unconditionally, the z stage never reads beyond sz)
+  float* xs = yr + 4 * 256;         // [window rows][sz] x-blended source rows
   __shared__ fsg_tap tb[ZT_MAX_TY];
   __shared__ int win[2];
   __shared__ float red[2][4];
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   }
   const bool dst16 = (Z.dz & 3) == 0 && ((((uintptr_t)Z.dst) & 15) == 0);
   const bool full = lane * 4 + 3 < Z.dz;
-  float* y = yr + wave * Z.sz;
+  float* y = yr + wave * 256;
   if (tid < 64) {
     fsg_tap t = fsg_tap{-1, 0, 0.f, 0.f};
     if (tid < nj) {
@@ -646,6 +647,14 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   }
   const UniDiv ud = unidiv_make(mx);
   const UniDiv udd = unidiv_make(den);  // the scaling's second divisor (1 - min/max) is uniform as well
+  // which arithmetic follows the first quotient (uniform): 0 none, 1 "* 0" (min == max), 2 "- min/max" (den == 1), 3 "(- min/max) / den"
+  // (min == 0, the usual case: "- 0" leaves every float as it is -> 0)
+  const int nmode = (EPI == EPI_NORM && E.norm_mode == 1) ? (mnq == 1.0f ? 1 : (den == 1.0f ? (mnq == 0.0f ? 0 : 2) : 3)) : 0;
+#ifdef FSG_NO_UNIDIV
+  const bool uni_ok = false;
+#else
+  const bool uni_ok = ud.fast && (nmode != 3 || udd.fast);
+#endif
   __syncthreads();
   auto row_tap = [&](int jj) {
     fsg_tap b = tb[jj];
@@ -675,23 +684,51 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = v[u] < 0.f ? 0.f : v[u];
     } else if (EPI == EPI_NORM) {
+      // The four quotients straight-line, ONE uniform test per row for "some lane left the fast division's domain" (then
+      // the row is redone by IEEE division: the same values, unidiv's contract).  Per element `ok ? q1 : v / d` compiled
+      // to a branch around an IEEE division per element and quotient: ~100 branch instructions per row in this loop.
+      float t[4];
+      bool bad = !uni_ok;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-#ifdef FSG_NO_UNIDIV
-        float t = v[u] / mx;
-#else
-        float t = unidiv(ud, v[u]);
-#endif
-        if (E.norm_mode == 1) t = (mnq == 1.0f) ? t * 0.0f : (den == 1.0f ? t - mnq : unidiv(udd, t - mnq));
-        v[u] = t;
+        const float q = v[u] * ud.r;
+        const float e = __builtin_fmaf(-q, ud.d, v[u]);
+        t[u] = __builtin_fmaf(e, ud.r, q);
+        bad |= !((q > 1e-18f && q < 1e18f) || v[u] == 0.f);
       }
+      if (nmode == 3) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = t[u] - mnq;
+          const float q = w * udd.r;
+          const float e = __builtin_fmaf(-q, udd.d, w);
+          t[u] = __builtin_fmaf(e, udd.r, q);
+          bad |= !((q > 1e-18f && q < 1e18f) || w == 0.f);
+        }
+      } else if (nmode == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = t[u] - mnq;
+      } else if (nmode == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = t[u] * 0.0f;
+      }
+      if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float tt = v[u] / mx;
+          if (E.norm_mode == 1) tt = (mnq == 1.0f) ? tt * 0.0f : (den == 1.0f ? tt - mnq : (tt - mnq) / den);
+          t[u] = tt;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = t[u];
     }
     if (EPI == EPI_MINMAX) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (lane * 4 + u < Z.dz) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
-    } else if (full && dst16) {
-      *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (dst16) {  // uniform (includes dz % 4 == 0: a lane's four outputs are all inside the row or all outside)
+      if (full) *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -713,10 +750,7 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
           h4[c] = xh[zs];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int zs = lane + 64 * c;
-          if (zs < Z.sz) y[zs] = fsg_mix(b.w_lo, l4[c], b.w_hi, h4[c]);
-        }
+        for (int c = 0; c < 4; ++c) y[lane + 64 * c] = fsg_mix(b.w_lo, l4[c], b.w_hi, h4[c]);  // (columns >= sz: padding, never read)
         zwave_sync();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -966,12 +1000,12 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     int TY = ty_pref < ZT_MAX_TY ? ty_pref : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;
     long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-    long long total = est + 4LL * Z.sz;  // window + the four waves' rows
+    long long total = est + 4LL * 256;  // window + the four waves' rows (padded to the domain's 256 columns)
     if (!(est <= g_zoom_cap && total <= 16000)) {
       TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
       if (TY > Z.dy) TY = Z.dy;
       est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-      total = est + 4LL * Z.sz;
+      total = est + 4LL * 256;
     }
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;
