@@ -613,6 +613,7 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   }
   const bool dst16 = (Z.dz & 3) == 0 && ((((uintptr_t)Z.dst) & 15) == 0);
   const bool full = lane * 4 + 3 < Z.dz;
+  const bool row4 = (Z.dz & 3) == 0;
   float* y = yr + wave * 256;
   if (tid < 64) {
     fsg_tap t = fsg_tap{-1, 0, 0.f, 0.f};
@@ -724,9 +725,17 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
       for (int u = 0; u < 4; ++u) v[u] = t[u];
     }
     if (EPI == EPI_MINMAX) {
+      if (row4) {  // uniform: dz % 4 == 0, a lane's four outputs are all inside the row or all outside -- min3 / max3 tree,
+                   // then one select against the identity (element by element this was 7 vector instructions per output:
+                   // fminf / fmaxf re-canonicalise both operands every time)
+        const float m0 = fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), m1 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        lo = fminf(lo, full ? m0 : INFINITY);
+        hi = fmaxf(hi, full ? m1 : -INFINITY);
+      } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (lane * 4 + u < Z.dz) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+        for (int u = 0; u < 4; ++u)
+          if (lane * 4 + u < Z.dz) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+      }
     } else if (dst16) {  // uniform (includes dz % 4 == 0: a lane's four outputs are all inside the row or all outside)
       if (full) *reinterpret_cast<float4*>(Z.dst + o0) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
@@ -744,10 +753,9 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
         const float* xh = xs + (b.hi - smin) * Z.sz;
         float l4[4], h4[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {  // all eight reads in flight before the first blend; indices clamped instead of predicated
-          const int zs = min(lane + 64 * c, Z.sz - 1);
-          l4[c] = xl[zs];
-          h4[c] = xh[zs];
+        for (int c = 0; c < 4; ++c) {  // all eight reads in flight before the first blend.  Columns >= sz read on into the next
+          l4[c] = xl[lane + 64 * c];   // window row or the 256 floats reserved behind the window: whatever they hold only reaches
+          h4[c] = xh[lane + 64 * c];   // the padding of y, which nobody reads -- one address per source row, the column an immediate
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) y[lane + 64 * c] = fsg_mix(b.w_lo, l4[c], b.w_hi, h4[c]);  // (columns >= sz: padding, never read)
@@ -1000,12 +1008,12 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     int TY = ty_pref < ZT_MAX_TY ? ty_pref : ZT_MAX_TY;
     if (TY > Z.dy) TY = Z.dy;
     long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-    long long total = est + 4LL * 256;  // window + the four waves' rows (padded to the domain's 256 columns)
+    long long total = est + 5LL * 256;  // window (+ 256 floats behind it: unclamped column reads) + the four waves' rows (256 each)
     if (!(est <= g_zoom_cap && total <= 16000)) {
       TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
       if (TY > Z.dy) TY = Z.dy;
       est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-      total = est + 4LL * 256;
+      total = est + 5LL * 256;
     }
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;

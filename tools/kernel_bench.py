@@ -19,10 +19,13 @@ ap.add_argument("--m", type=int, default=171, help="low-res size for the resampl
 ap.add_argument("--rot", type=float, default=12.0, help="rotation (degrees) about each axis")
 ap.add_argument("--tune", type=int, default=0, help="fsg_set_tuning flags")
 ap.add_argument("--variant", type=int, default=0, help="fsg_warp_set_variant")
+ap.add_argument("--zoom-ty", type=int, default=0, help="fsg_zoom_set_tuning: output rows per workgroup (0 = default)")
 args = ap.parse_args()
 dev = "cuda:0"
 from fetalsyngen_amd import _lib
 _lib.load().fsg_set_tuning(args.tune)
+if args.zoom_ty:
+    _lib.check(_lib.load().fsg_zoom_set_tuning(args.zoom_ty, 12000), "fsg_zoom_set_tuning")
 _lib.load().fsg_warp_set_variant(args.variant)
 n = args.size
 shape = (n, n, n)
