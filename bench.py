@@ -731,7 +731,7 @@ def run(args, rank, world, local):
                                    "(volume read once, x-resampled volume written once), fused y,z launch 4N m/n + 4M (M = "
                                    "low-res voxels of that sample); unfused launches 8 B/voxel.  traffic = those bytes x the "
                                    "traffic/algorithmic ratio of the launch's kernel in the committed PMC table "
-                                   "(profiles/r03_d_blur_rs_pmc.json: 1.00-1.03)",
+                                   f"(profiles/{rs_files[-1].name if rs_files else 'none'}: 1.00-1.03)",
                      "samples_fused": n_fused, "samples_timed": len(sections),
                      "axis_passes_per_sample": round(npass / max(len(sections), 1), 2),
                      "launches_per_sample": round(nlaunch / max(len(sections), 1), 2)},
