@@ -9,7 +9,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libfsg_hip.so"
-SOURCES = ["fsg_deform.hip", "fsg_warp_lean.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_blur_rs.hip", "fsg_reduce.hip", "fsg_slice_acq.hip", "fsg_artifacts.hip", "fsg_keyed.hip",
+SOURCES = ["fsg_deform.hip", "fsg_warp_lean.hip", "fsg_zoom.hip", "fsg_intensity.hip", "fsg_blur.hip", "fsg_blur_rs.hip", "fsg_reduce.hip", "fsg_slice_acq.hip", "fsg_artifacts.hip", "fsg_keyed.hip", "fsg_codes.hip",
            "fsg_pipeline.cpp"]
 EXTRA = os.environ.get("FSG_EXTRA_FLAGS", "").split()
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("FSG_LIB", PKG / "libfsg_hip.so"))  # FSG_LIB: A/B another build of the same ABI
 
 E_BADARG, E_TOOBIG, E_ALIGN = -1, -2, -3
-ABI_VERSION = 2  # include/fsg_hip.h: FSG_ABI_VERSION
+ABI_VERSION = 3  # include/fsg_hip.h: FSG_ABI_VERSION
 
 
 class FsgError(RuntimeError):
@@ -105,6 +105,11 @@ class SamplePlan(C.Structure):
         ("trace_cap", C.c_int32),
         ("trace_start", C.c_int32),
         ("trace_first_id", C.c_int32),
+        ("label_codes", C.c_void_p),
+        ("code_tuples", C.c_void_p),
+        ("code_ntuples", C.c_int32),
+        ("code_stride", C.c_int32),
+        ("code_sel", C.c_int32 * 4),
     ]
 
 
@@ -146,7 +151,7 @@ E_NOTABLE = -4
 KT_RESAMPLE, KT_BACK, KT_FIELD, KT_BIAS = 0, 1, 2, 3
 KEYED_I = dict(KEY=0, OUT=1, SEG_OUT=2, SEG_OUT_U8=3, SEG_IN=4, SEG_IN_U8=5, BLOCK=6, WS0=7, WS1=8, WS_LOW=9, WS_ROWS=10,
                ROW_STRIDE=11, SCALE01=12, TRACE_EVENTS=13, TRACE_IDS=14, TRACE_CAP=15, BANK=16, EV_BLUR_BEGIN=80,
-               EV_BLUR_END=81, COUNT=82)
+               EV_BLUR_END=81, CODES=82, CODE_TUPLES=83, CODE_NTUPLES=84, CODE_STRIDE=85, COUNT=86)
 
 STAGE_NAMES = ("begin", "upload", "draw", "head", "floormin", "warp", "blur_x", "blur_y", "blur_z", "blur_yz", "k7", "k9a", "k9b",
                "gmm", "rows", "pointwise", "blur_rs_x", "blur_rs_yz")  # include/fsg_hip.h: FSG_ST_*
@@ -212,6 +217,8 @@ SIGNATURES = {
     "fsg_copy_bytes": [P, P, SZ, P],
     "fsg_zoom_set_tuning": [I, I],
     "fsg_sample_head_f32": [P, P, P, P, SZ, P, P, I, P, U64, U64, P, C.POINTER(Deform), C.POINTER(Epilogue), P, I, P, P],
+    "fsg_seed_codes_build": [P, I, SZ, I, P, P, I, P, SZ, P, P],
+    "fsg_sample_head_codes_f32": [P, P, I, I, C.POINTER(C.c_int32), SZ, P, P, I, U64, U64, P, C.POINTER(Deform), C.POINTER(Epilogue), P, I, P, P],
     "fsg_coords_floormin_rest_f32": [C.POINTER(Deform), P, P],
     "fsg_sample_run": [C.POINTER(SamplePlan), P],
     "fsg_sample_plan_pack": [C.POINTER(SamplePlan), P, I, P, I, P],
@@ -235,7 +242,7 @@ SIGNATURES = {
 }
 SPECIAL_RESTYPE = {"fsg_error_string": (C.c_char_p, [I]), "fsg_key_to_float": (F, [C.c_int32]),
                    "fsg_event_create": (C.c_void_p, []), "fsg_sample_plan_layout": (C.c_int64, [I]),
-                   "fsg_keyed_block_bytes": (C.c_int64, [P])}
+                   "fsg_keyed_block_bytes": (C.c_int64, [P]), "fsg_seed_codes_work_bytes": (C.c_size_t, [])}
 
 _lib = None
 

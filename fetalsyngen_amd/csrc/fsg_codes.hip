@@ -1,0 +1,110 @@
+// The seed volumes of a subject as one uint16 code volume (include/fsg_hip.h: fsg_seed_codes_build, fsg_sample_head_codes_f32).
+//
+// Reference: ImageFromSeeds.load_seeds (intensity/rand_gmm.py:91-99) adds up one label volume per meta label for every sample;
+// the volumes a sample can select from are fixed per subject.  A voxel's "column" -- the byte every seed volume holds there --
+// takes few distinct values per subject (its meta label and its sub-cluster under every sub-cluster count), so the column's
+// index is a 2-byte code and a sample's label a table look-up.  This file builds codes + distinct columns in one pass: an exact
+// hash set of columns in global memory (open addressing; a slot is claimed with one atomicCAS, published with its code, and
+// compared word by word on a hit -- the hash only picks the first slot), sized for at most FSG_CODES_MAX columns.
+#include "fsg_common.h"
+
+namespace {
+
+constexpr int SC_SLOTS = 8192;      // power of two, 4 x FSG_CODES_MAX
+constexpr int SC_WORDS = 16;        // a column padded to 64 bytes (nparts <= 64)
+constexpr int SC_MAXPARTS = 64;
+
+struct CodesK {
+  const uint8_t* part[SC_MAXPARTS];
+  int nparts, nwords, stride, cap;
+  uint32_t n;
+  uint16_t* codes;
+  uint8_t* tuples;     // [cap][stride], zero-initialised by the host side
+  int32_t* state;      // [SC_SLOTS] 0 empty, 1 being written, 2 ready
+  int32_t* slot_code;  // [SC_SLOTS]
+  uint32_t* slot_col;  // [SC_SLOTS][SC_WORDS]
+  int32_t* count;      // distinct columns so far (may run past cap: then the result is unusable and the caller is told)
+};
+
+__global__ __launch_bounds__(256) void seed_codes_kernel(const CodesK P) {
+  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < P.n; v += gridDim.x * 256u) {
+    uint32_t col[SC_WORDS];
+#pragma unroll
+    for (int w = 0; w < SC_WORDS; ++w) col[w] = 0u;
+    uint32_t h = 2166136261u;
+#pragma unroll
+    for (int w = 0; w < SC_WORDS; ++w) {
+      if (w < P.nwords) {  // uniform
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int j = 4 * w + b;
+          if (j < P.nparts) col[w] |= (uint32_t)P.part[j][v] << (8 * b);
+        }
+        h = (h ^ col[w]) * 16777619u;
+        h ^= h >> 15;
+      }
+    }
+    uint32_t slot = h & (SC_SLOTS - 1);
+    int code = -1;
+    // every lane completes whatever it starts inside ONE trip of this loop (the lane that claims a slot writes and publishes
+    // it before the trip ends), so lanes of one wave that wait for each other's slot cannot dead-lock
+    for (int guard = 0; guard < 64 * SC_SLOTS && code < 0; ++guard) {
+      const int st = __hip_atomic_load(&P.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (st == 2) {
+        bool same = true;
+        for (int w = 0; w < P.nwords; ++w) same = same && P.slot_col[(size_t)slot * SC_WORDS + w] == col[w];
+        if (same) code = P.slot_code[slot];
+        else slot = (slot + 1) & (SC_SLOTS - 1);
+      } else if (st == 0) {
+        if (atomicCAS(&P.state[slot], 0, 1) == 0) {
+          const int c = atomicAdd(P.count, 1);
+          for (int w = 0; w < P.nwords; ++w) P.slot_col[(size_t)slot * SC_WORDS + w] = col[w];
+          P.slot_code[slot] = c;
+          if (c < P.cap)
+            for (int j = 0; j < P.nparts; ++j) P.tuples[(size_t)c * P.stride + j] = (uint8_t)(col[j >> 2] >> (8 * (j & 3)));
+          __hip_atomic_store(&P.state[slot], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          code = c;
+        }
+      }  // st == 1: another lane is writing this slot -- look again
+      if (__hip_atomic_load(P.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > SC_SLOTS / 2) break;  // table filling up: give up
+    }
+    P.codes[v] = (uint16_t)(code < 0 || code >= P.cap ? 0 : code);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fsg_seed_codes_work_bytes(void) { return (size_t)SC_SLOTS * (2 * sizeof(int32_t) + SC_WORDS * sizeof(uint32_t)) + 64; }
+
+int fsg_seed_codes_build(const uint8_t* const* parts, int nparts, size_t n, int stride, uint16_t* codes, uint8_t* tuples, int cap,
+                         void* work, size_t work_bytes, int32_t* count_dev, void* stream) {
+  if (!parts || nparts <= 0 || nparts > SC_MAXPARTS || n == 0 || !codes || !tuples || !work || !count_dev) return FSG_E_BADARG;
+  if (stride <= nparts || stride > 256 || cap <= 0 || cap > FSG_CODES_MAX) return FSG_E_BADARG;
+  if (n > ((size_t)1 << 30)) return FSG_E_TOOBIG;
+  if (work_bytes < fsg_seed_codes_work_bytes() || ((uintptr_t)work & 15)) return FSG_E_BADARG;
+  for (int j = 0; j < nparts; ++j)
+    if (!parts[j]) return FSG_E_BADARG;
+  hipStream_t st = fsg_stream(stream);
+  hipError_t e = hipMemsetAsync(work, 0, fsg_seed_codes_work_bytes(), st);
+  if (e == hipSuccess) e = hipMemsetAsync(tuples, 0, (size_t)cap * stride, st);
+  if (e == hipSuccess) e = hipMemsetAsync(count_dev, 0, sizeof(int32_t), st);
+  if (e != hipSuccess) return (int)e;
+  CodesK P;
+  for (int j = 0; j < SC_MAXPARTS; ++j) P.part[j] = j < nparts ? parts[j] : nullptr;
+  P.nparts = nparts; P.nwords = (nparts + 3) / 4; P.stride = stride; P.cap = cap;
+  P.n = (uint32_t)n;
+  P.codes = codes; P.tuples = tuples;
+  char* w = (char*)work;
+  P.state = (int32_t*)w;
+  P.slot_code = (int32_t*)(w + (size_t)SC_SLOTS * sizeof(int32_t));
+  P.slot_col = (uint32_t*)(w + (size_t)SC_SLOTS * 2 * sizeof(int32_t));
+  P.count = count_dev;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(seed_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P);
+  FSG_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -403,6 +403,9 @@ struct HeadGmm {
   const float* mus; const float* sigmas; int ntab;
   const float* noise; uint64_t seed, stream_id;
   float* out;
+  // codes mode (ntuples > 0): l0 = the uint16 code volume, l1 = the tuples, sel = the four selected bytes of a row (8 bits each)
+  int ntuples, stride;
+  uint32_t sel;
 };
 
 // 8 waves/SIMD (<= 64 VGPRs) as the stand-alone GMM kernel has: the face job alone would take 73 and cap the launch at 6
@@ -411,7 +414,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                           int32_t* __restrict__ mm3) {
   __shared__ float s_mu[256], s_sg[256];
   __shared__ float red[3][4];
-  __shared__ RowsSmem S;
+  union HeadSmem {  // a workgroup does one job: the rows job's block and the codes mode's (mu, sigma) table share the space
+    RowsSmem rows;
+    float2 code_ms[FSG_CODES_MAX];
+  };
+  __shared__ HeadSmem U;
+  RowsSmem& S = U.rows;
   int b = blockIdx.x;  // workgroup-uniform branches: a workgroup does exactly one of the three jobs
   if (b < nfaces) {  // the longest dependent chain first
     coords_faces_min_body(D, mm3, red, b, nfaces);
@@ -423,6 +431,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     return;
   }
   b -= nrows;
+  if (G.ntuples > 0) {
+    // codes mode: (mu, sigma) of every code of the subject under this sample's selection, then 2 + 4 bytes per voxel
+    const uint8_t* __restrict__ tup = G.l1;
+    for (int c = threadIdx.x; c < G.ntuples; c += blockDim.x) {
+      const uint8_t* row = tup + (size_t)c * G.stride;
+      const int lab = (row[G.sel & 255u] + row[(G.sel >> 8) & 255u] + row[(G.sel >> 16) & 255u] + row[G.sel >> 24]) & 255;
+      U.code_ms[c] = lab < G.ntab ? make_float2(G.mus[lab], G.sigmas[lab]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const uint32_t ng = (uint32_t)(G.n >> 2), nb = gridDim.x - (unsigned)(nrows + nfaces), step = nb * blockDim.x;
+    const uint8_t* __restrict__ codes = G.l0;
+    for (uint32_t g = (uint32_t)b * blockDim.x + threadIdx.x; g < ng; g += step) {
+      const uint2 w = *reinterpret_cast<const uint2*>(codes + (size_t)(g << 3));  // four uint16 codes
+      const float4 r = fsg_randn4<true>(G.seed, G.stream_id, (uint64_t)g);
+      const float2 m0 = U.code_ms[w.x & 0xFFFFu], m1 = U.code_ms[w.x >> 16], m2 = U.code_ms[w.y & 0xFFFFu], m3 = U.code_ms[w.y >> 16];
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(G.out) + (size_t)(g << 4)) =
+          make_float4(fmaxf(m0.x + m0.y * r.x, 0.f), fmaxf(m1.x + m1.y * r.y, 0.f), fmaxf(m2.x + m2.y * r.z, 0.f),
+                      fmaxf(m3.x + m3.y * r.w, 0.f));
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < 256; t += blockDim.x) {
     s_mu[t] = t < G.ntab ? G.mus[t] : 0.f;
     s_sg[t] = t < G.ntab ? G.sigmas[t] : 0.f;
@@ -1594,6 +1623,9 @@ int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream
   FSG_RETURN_LAUNCH();
 }
 
+static int launch_sample_head(const HeadGmm& G, size_t n, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
+                              int row_stride, int32_t* mm3, void* stream);
+
 int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
                         const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,
                         uint64_t stream_id, float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
@@ -1601,6 +1633,27 @@ int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2,
   if (n == 0 || !l0 || !mus || !sigmas || !out || ntab <= 0 || ntab > 256 || !mm3) return FSG_E_BADARG;
   const uintptr_t al = (uintptr_t)l0 | (uintptr_t)l1 | (uintptr_t)l2 | (uintptr_t)l3;
   if ((al & 3) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
+  HeadGmm G{l0, l1, l2, l3, n, mus, sigmas, ntab, noise, seed, stream_id, out, 0, 0, 0u};
+  return launch_sample_head(G, n, d, epi, rows, row_stride, mm3, stream);
+}
+
+int fsg_sample_head_codes_f32(const uint16_t* codes, const uint8_t* tuples, int ntuples, int stride, const int32_t sel[4],
+                              size_t n, const float* mus, const float* sigmas, int ntab, uint64_t seed, uint64_t stream_id,
+                              float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows, int row_stride,
+                              int32_t* mm3, void* stream) {
+  if (n == 0 || !codes || !tuples || !sel || !mus || !sigmas || !out || ntab <= 0 || ntab > 256 || !mm3) return FSG_E_BADARG;
+  if (ntuples <= 0 || stride <= 0 || stride > 256) return FSG_E_BADARG;
+  for (int m = 0; m < 4; ++m)
+    if (sel[m] < 0 || sel[m] >= stride) return FSG_E_BADARG;
+  if (ntuples > FSG_CODES_MAX || n > ((size_t)1 << 30)) return FSG_E_TOOBIG;
+  if ((n & 3) || ((uintptr_t)codes & 7) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
+  HeadGmm G{reinterpret_cast<const uint8_t*>(codes), tuples, nullptr, nullptr, n, mus, sigmas, ntab, nullptr, seed, stream_id, out,
+            ntuples, stride, (uint32_t)sel[0] | ((uint32_t)sel[1] << 8) | ((uint32_t)sel[2] << 16) | ((uint32_t)sel[3] << 24)};
+  return launch_sample_head(G, n, d, epi, rows, row_stride, mm3, stream);
+}
+
+static int launch_sample_head(const HeadGmm& G, size_t n, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
+                              int row_stride, int32_t* mm3, void* stream) {
   FsgDeformK D;
   int rc = fsg_fill_deform(d, D);
   if (rc) return rc;
@@ -1620,7 +1673,6 @@ int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2,
   size_t ngmm = ((n + 3) / 4 + 255) / 256;
   if (ngmm > 4096) ngmm = 4096;  // 4 groups per thread: 33.8 us (8 192: 34.8, 16 384: 39.0)
   if (nrows > 1000000) return FSG_E_TOOBIG;
-  HeadGmm G{l0, l1, l2, l3, n, mus, sigmas, ntab, noise, seed, stream_id, out};
   hipLaunchKernelGGL(sample_head_kernel, dim3((unsigned)(nrows + nfaces + ngmm)), dim3(256), 0, fsg_stream(stream), G, D,
                      E, rows, row_stride, rows_gx > 0 ? rows_gx : 1, (int)nrows, nfaces, mm3);
   FSG_RETURN_LAUNCH();

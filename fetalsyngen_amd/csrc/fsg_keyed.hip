@@ -367,6 +367,15 @@ int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws*
     q.label_parts[m] = (const uint8_t*)(uintptr_t)iv[FSG_KEYED_I_BANK + 4 * (d.subclusters[m] - c.min_subclusters) + m];
     if (!q.label_parts[m]) return FSG_E_BADARG;
   }
+  if (iv[FSG_KEYED_I_CODES] && iv[FSG_KEYED_I_CODE_TUPLES]) {  // the subject's code volume: selection = one byte of a tuple per meta label
+    q.label_codes = (const uint16_t*)(uintptr_t)iv[FSG_KEYED_I_CODES];
+    q.code_tuples = (const uint8_t*)(uintptr_t)iv[FSG_KEYED_I_CODE_TUPLES];
+    q.code_ntuples = (int32_t)iv[FSG_KEYED_I_CODE_NTUPLES];
+    q.code_stride = (int32_t)iv[FSG_KEYED_I_CODE_STRIDE];
+    if (q.code_stride < 4 * (c.max_subclusters - c.min_subclusters + 1) + 1) return FSG_E_BADARG;
+    for (int m = 0; m < 4; ++m)
+      q.code_sel[m] = m < c.meta_labels ? 4 * (d.subclusters[m] - c.min_subclusters) + m : q.code_stride - 1;
+  }
   q.mus = (const float*)(base + d.off_mus);
   q.sigmas = (const float*)(base + d.off_sigmas);
   q.ntab = d.ntab;

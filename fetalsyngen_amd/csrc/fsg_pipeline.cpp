@@ -146,9 +146,15 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     // K1 + per-row coarse values + six-face minimum in one launch (keys arrive initialised with the parameters)
     dh.rows = nullptr;
     dh.row_stride = 0;
-    head_rc = fsg_sample_head_f32(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
-                                  p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
-                                  p->ws_rows, p->row_stride, p->mm8, hstream);
+    head_rc = FSG_E_ALIGN;
+    if (p->label_codes && p->code_tuples && !p->gmm_noise && !(g_tuning_flags & FSG_TUNE_NO_SEED_CODES))  // 6 instead of 8 B/voxel
+      head_rc = fsg_sample_head_codes_f32(p->label_codes, p->code_tuples, p->code_ntuples, p->code_stride, p->code_sel, n, p->mus,
+                                          p->sigmas, p->ntab, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi, p->ws_rows,
+                                          p->row_stride, p->mm8, hstream);
+    if (head_rc == FSG_E_ALIGN || head_rc == FSG_E_TOOBIG)  // no codes, or outside their domain: the four label volumes
+      head_rc = fsg_sample_head_f32(p->label_parts[0], p->label_parts[1], p->label_parts[2], p->label_parts[3], n, p->mus,
+                                    p->sigmas, p->ntab, p->gmm_noise, p->gmm_seed, p->gmm_stream, p->ws0, &dh, &p->epi,
+                                    p->ws_rows, p->row_stride, p->mm8, hstream);
     if (head_rc == 0) head_done = true;
     if (head_done && !ho) FSG_TRY(mark(FSG_ST_HEAD));
   }
@@ -321,6 +327,7 @@ extern "C" int64_t fsg_sample_plan_layout(int which) {
     case 2: return (int64_t)offsetof(fsg_sample_plan, out);
     case 3: return (int64_t)offsetof(fsg_sample_plan, seg_in_u8);
     case 4: return (int64_t)offsetof(fsg_sample_plan, ws_seq);
+    case 5: return (int64_t)offsetof(fsg_sample_plan, code_sel);
     default: return -1;
   }
 }

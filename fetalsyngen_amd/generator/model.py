@@ -323,6 +323,12 @@ class FetalSynthGen:
         (`_version`); it cannot notice a label volume rewritten through its raw pointer (another HIP library, the `fsg_*`
         entry points themselves) -- call this after such a write."""
         self.__dict__.pop("_twins", None)
+        for kc in (self.__dict__.get("_keyed") or {}).values():  # keyed mode: the subjects' pointer blocks and code volumes
+            for hit in kc._subjects.values():
+                bank = hit[0]()
+                if bank is not None:
+                    bank.__dict__.pop("_seed_codes", None)
+            kc._subjects.clear()
         fb = self.__dict__.get("_flat")
         if fb is not None:
             fb["validated"].clear()
@@ -998,10 +1004,11 @@ class FetalSynthGen:
             if self._blur_tick % self.blur_events_every == 0:
                 events = (kc.lib.fsg_event_create(), kc.lib.fsg_event_create())
         iv[80], iv[81] = events if events is not None else (0, 0)
+        iv[82], iv[83], iv[84], iv[85] = ent[3], ent[4], ent[5], ent[6]  # the subject's code volume (0: four label volumes)
         d = _lib.KeyedDraws()
         import ctypes as C
 
-        rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, 82, C.byref(d), K._stream(dev))
+        rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, len(kc.iv), C.byref(d), K._stream(dev))
         if events is not None:
             if rc == 0 and d.resample_active:
                 self.blur_events.append((events[0], events[1], [(a_, int(d.blur_ntaps[a_]) // 2) for a_ in range(3) if d.blur_ntaps[a_]],

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib
 from . import kernels as K
+from . import seedcodes
 from . import tables as T
 
 
@@ -76,6 +77,7 @@ class KeyedContext:
         self.iv = np.zeros(_lib.KEYED_I["COUNT"], dtype=np.int64)
         self.ivp = self.iv.ctypes.data
         self._subjects = {}
+        self.use_codes = True  # the subject's seed volumes as one uint16 code volume (seedcodes.py, built on first use)
         self._tables_ready = False
         self._keep = []  # device tables registered with the context
         # rows of the per-(x,y) coarse workspace the largest grids need (3 * field_dims[2] + bias_dims[2])
@@ -128,9 +130,11 @@ class KeyedContext:
         key = (id(bank), id(seg))
         hit = self._subjects.get(key)
         if hit is not None and hit[0]() is bank and hit[1]() is seg and hit[2] == seg._version:
-            if twin is not None and hit[3][1] == 0:
-                hit[3][1] = twin.data_ptr()
-            return hit[3]
+            ent = hit[3]
+            if twin is not None and ent[1] == 0:
+                ent[1] = twin.data_ptr()
+            self._codes(bank, ent)  # (built once per bank object; a rewrite of a seed volume through torch rebuilds it)
+            return ent
         c, shape = self.cfg, self.shape
         dev = torch.device(self.device)
         if tuple(seg.shape) != shape or seg.dtype != torch.float32 or not seg.is_cuda or not seg.is_contiguous():
@@ -145,11 +149,46 @@ class KeyedContext:
                     raise ValueError(f"seed volume ({n}, {m}): expected a contiguous uint8 tensor of shape {shape} on {dev}, "
                                      f"got {part.dtype} {tuple(part.shape)} on {part.device}")
                 ptrs[4 * (n - c.min_subclusters) + (m - 1)] = part.data_ptr()
-        ent = [ptrs, 0 if twin is None else twin.data_ptr(), seg.data_ptr()]
+        ent = [ptrs, 0 if twin is None else twin.data_ptr(), seg.data_ptr(), 0, 0, 0, 0]  # .. codes, tuples, ntuples, stride
+        self._codes(bank, ent)  # ~0.5 ms once per bank object (one pass over its volumes), nothing next to loading the subject
         if len(self._subjects) > 4096:
             self._subjects.clear()
         self._subjects[key] = (weakref.ref(bank), weakref.ref(seg), seg._version, ent)
         return ent
+
+    def _codes(self, bank, ent):
+        """ent[3:7] = the subject's code volume (seedcodes.build), kept ON the bank object so that it lives and dies with it.
+        A seed volume rewritten through torch bumps its `_version`: the codes are rebuilt; a rewrite through a raw pointer needs
+        `FetalSynthGen.invalidate_label_twins()` (which drops them)."""
+        if not self.use_codes:
+            ent[3:7] = [0, 0, 0, 0]
+            return
+        c = self.cfg
+        vol = bank.vol
+        parts = [vol[n][m] for n in range(c.min_subclusters, c.max_subclusters + 1) for m in range(1, c.meta_labels + 1)]
+        ver = sum(p._version for p in parts)
+        have = getattr(bank, "_seed_codes", None)
+        if have is None or have[0] != ver or have[1] != self.shape:
+            cols = []
+            for n in range(c.min_subclusters, c.max_subclusters + 1):
+                for m in range(1, 5):
+                    cols.append(vol[n][m] if m <= c.meta_labels else None)
+            stride = len(cols) + 1
+            zero = None
+            dense = []
+            for col in cols:
+                if col is None:
+                    zero = torch.zeros_like(parts[0]) if zero is None else zero
+                    col = zero
+                dense.append(col)
+            built = seedcodes.build_device(dense, stride) if (parts[0].numel() % 4 == 0 and parts[0].numel() <= (1 << 30)) else None
+            have = (ver, self.shape, built, stride)
+            bank._seed_codes = have
+        built = have[2]
+        if built is None:
+            ent[3:7] = [0, 0, 0, 0]
+        else:
+            ent[3:7] = [built[0].data_ptr(), built[1].data_ptr(), int(built[1].shape[0]), int(have[3])]
 
     def draws(self, key: int) -> _lib.KeyedDraws:
         d = _lib.KeyedDraws()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FSG_ABI_VERSION 2  /* 2: fsg_sample_plan grew (mm_slots .. seg_out_u8) after version 1 shipped */
+#define FSG_ABI_VERSION 3  /* 2: fsg_sample_plan grew (mm_slots .. seg_out_u8) after version 1 shipped; 3: label_codes .. code_sel, FSG_KEYED_I_CODES */
 
 #define FSG_E_BADARG (-1)   /* null pointer / non-positive size / bad enum */
 #define FSG_E_TOOBIG (-2)   /* size exceeds what the kernel indexes (2^31-1 voxels per volume) */
@@ -82,6 +82,7 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_SPLIT_HEAD 2048 /* fsg_sample_run: GMM draw, per-row coarse values and six-face minimum as three launches */
 #define FSG_TUNE_SLAB_ZOOM 8192 /* the slab zoom kernel also for the noise epilogues (default there: tile kernel) */
 #define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
+#define FSG_TUNE_NO_SEED_CODES 65536 /* A/B: the one-launch head reads the four label volumes even when the plan carries a code volume */
 #define FSG_TUNE_WAVE_ZOOM 32768 /* opt in: zooms without a noise draw through the wave kernel (independent waves; slower in r03) */
 #define FSG_TUNE_NO_BLUR_RS 16384 /* fsg_sample_run: blur x3 + K7 as separate launches instead of the fused blur+resample pair */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */
@@ -386,6 +387,29 @@ int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2,
                         uint64_t stream_id, float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
                         int row_stride, int32_t* mm3, void* stream);
 int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream);
+/* The same launch with the seed labels of a subject as ONE uint16 code volume instead of four uint8 volumes (6 instead of 8
+ * bytes per voxel): codes[v] indexes `tuples`, ntuples rows of `stride` bytes, row c = the value every seed volume of the
+ * subject holds at the voxels with code c (built once per subject by the caller: the distinct columns of the stacked seed
+ * volumes); sel[m] = the byte of a row that belongs to the volume selected for meta label m (a zero byte for an absent one).
+ * label = (tuples[c][sel[0]] + .. + tuples[c][sel[3]]) & 255 -- what fsg_sample_head_f32 adds up voxel by voxel
+ * (rand_gmm.py:91-99) -- so the output is bit-identical.  n % 4 == 0, n <= 2^30, ntuples <= FSG_CODES_MAX, Philox noise only;
+ * otherwise FSG_E_ALIGN / FSG_E_TOOBIG and the caller uses fsg_sample_head_f32. */
+#define FSG_CODES_MAX 2048
+int fsg_sample_head_codes_f32(const uint16_t* codes, const uint8_t* tuples, int ntuples, int stride, const int32_t sel[4],
+                              size_t n, const float* mus, const float* sigmas, int ntab, uint64_t seed, uint64_t stream_id,
+                              float* out, const fsg_deform* d, const fsg_epilogue* epi, float* rows, int row_stride,
+                              int32_t* mm3, void* stream);
+
+/* Builds codes (n uint16) and tuples (cap rows of `stride` bytes; row c, byte j = the value of parts[j] at the voxels with code
+ * c; bytes >= nparts stay 0) from the nparts <= 64 uint8 volumes of a subject in one pass (csrc/fsg_codes.hip).  parts: HOST
+ * array of device pointers.  work: fsg_seed_codes_work_bytes() of device scratch (16-byte aligned).  *count_dev receives the
+ * number of distinct columns: usable only if it is <= cap (<= FSG_CODES_MAX) -- read it after synchronising.  The numbering of
+ * the codes depends on the order in which the lanes met the columns (run to run); codes and tuples are consistent with each
+ * other, which is all fsg_sample_head_codes_f32 needs.  No reference counterpart: the reference re-reads and adds up the four
+ * selected NIfTI volumes per sample (rand_gmm.py:91-99). */
+size_t fsg_seed_codes_work_bytes(void);
+int fsg_seed_codes_build(const uint8_t* const* parts, int nparts, size_t n, int stride, uint16_t* codes, uint8_t* tuples, int cap,
+                         void* work, size_t work_bytes, int32_t* count_dev, void* stream);
 
 typedef struct fsg_sample_plan {
   int32_t shape[3];
@@ -460,6 +484,12 @@ typedef struct fsg_sample_plan {
   int32_t trace_start;           /* events the caller has already recorded (fsg_keyed_sample_run: 1, the one before its draw
                                   * kernel); the first event of this call then carries trace_first_id instead of FSG_ST_BEGIN */
   int32_t trace_first_id;
+  /* optional (ABI 3): the subject's seed labels as one code volume (fsg_sample_head_codes_f32); label_parts stay valid and are
+   * what every path without the one-launch head reads */
+  const uint16_t* label_codes;
+  const uint8_t* code_tuples;
+  int32_t code_ntuples, code_stride;
+  int32_t code_sel[4];
 } fsg_sample_plan;
 enum {
   FSG_ST_BEGIN = 0, FSG_ST_UPLOAD = 1, FSG_ST_DRAW = 2, FSG_ST_HEAD = 3, FSG_ST_FLOORMIN = 4, FSG_ST_WARP = 5, FSG_ST_BLUR_X = 6,
@@ -594,7 +624,11 @@ enum {
   FSG_KEYED_I_SEG_IN_U8 = 5, FSG_KEYED_I_BLOCK = 6, FSG_KEYED_I_WS0 = 7, FSG_KEYED_I_WS1 = 8, FSG_KEYED_I_WS_LOW = 9,
   FSG_KEYED_I_WS_ROWS = 10, FSG_KEYED_I_ROW_STRIDE = 11, FSG_KEYED_I_SCALE01 = 12, FSG_KEYED_I_TRACE_EVENTS = 13,
   FSG_KEYED_I_TRACE_IDS = 14, FSG_KEYED_I_TRACE_CAP = 15, FSG_KEYED_I_BANK = 16, FSG_KEYED_I_EV_BLUR_BEGIN = 16 + 64,
-  FSG_KEYED_I_EV_BLUR_END = 16 + 65, FSG_KEYED_I_COUNT = 16 + 66
+  FSG_KEYED_I_EV_BLUR_END = 16 + 65,
+  /* optional code volume of the subject (0 = none): uint16 codes, uint8 tuples [ntuples][stride] whose byte
+   * 4 * (n_sub - min_subclusters) + (mlabel - 1) is the value of seed volume (n_sub, mlabel) and whose byte stride - 1 is 0 */
+  FSG_KEYED_I_CODES = 16 + 66, FSG_KEYED_I_CODE_TUPLES = 16 + 67, FSG_KEYED_I_CODE_NTUPLES = 16 + 68, FSG_KEYED_I_CODE_STRIDE = 16 + 69,
+  FSG_KEYED_I_COUNT = 16 + 70
 };
 int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws* draws_out, void* stream);
 /* The draw kernel alone (tests): fills the parameter block of `draws` at block_dev. */

@@ -93,4 +93,5 @@ def test_sample_plan_mirror_has_the_c_layout():
     assert lib.fsg_sample_plan_layout(2) == P.out.offset
     assert lib.fsg_sample_plan_layout(3) == P.seg_in_u8.offset
     assert lib.fsg_sample_plan_layout(4) == P.ws_seq.offset
+    assert lib.fsg_sample_plan_layout(5) == P.code_sel.offset
     assert lib.fsg_sample_plan_layout(99) == -1

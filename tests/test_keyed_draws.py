@@ -308,3 +308,106 @@ def test_keyed_samples_depend_on_the_key_only(K):
     bank, seg, _t = ds._subject(0)
     _o, _s, _i, p_dev = gen3._pipeline(None, seg, bank, {}, scale01=True)
     assert set(p_dev) <= set(ref[0][3]) and set(ref[0][3]) - set(p_dev) == {"key"}
+
+
+# ---- the subject's seed volumes as one code volume (fetalsyngen_amd/seedcodes.py, fsg_sample_head_codes_f32) --------------------
+def _phantom_parts(shape, variant=0):
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    _seg, seeds = make_seed_volumes(shape, variant)
+    return [torch.from_numpy(seeds[n][m].astype(np.uint8)) for n in range(1, 7) for m in range(1, 5)]
+
+
+def test_seed_codes_stand_for_the_byte_wise_sum_of_the_selected_volumes():
+    """reference rand_gmm.py:91-99: the seed label map is the sum of one volume per meta label; the code volume + tuple rows
+    give the same labels for every selection."""
+    from fetalsyngen_amd import seedcodes as SC
+
+    parts = _phantom_parts((40, 36, 28), 1)
+    codes, tuples = SC.build(parts, 25)
+    assert codes.dtype == torch.int16 and tuples.dtype == torch.uint8 and tuples.shape[1] == 25
+    assert int(codes.max()) + 1 == tuples.shape[0] <= SC.CODES_MAX and (tuples[:, 24] == 0).all()
+    rs = np.random.RandomState(3)
+    for _ in range(8):
+        ns = rs.randint(1, 7, 4)
+        sel = [4 * (ns[m] - 1) + m for m in range(4)]
+        want = (sum(parts[s].to(torch.int64) for s in sel) & 255).to(torch.uint8)
+        assert torch.equal(SC.labels_of(codes, tuples, sel), want)
+    # three meta labels: the fourth selects the zero byte of a row
+    sel3 = [0, 4 * 2 + 1, 4 * 5 + 2, 24]
+    assert torch.equal(SC.labels_of(codes, tuples, sel3), (sum(parts[s].to(torch.int64) for s in sel3[:3]) & 255).to(torch.uint8))
+    # more distinct columns than a workgroup's table holds: no codes (the caller keeps the four volumes)
+    wide = [torch.arange(4096, dtype=torch.int64).remainder(256).to(torch.uint8), (torch.arange(4096) // 256).to(torch.uint8)]
+    assert SC.build(wide, 3) is None
+    with pytest.raises(ValueError):
+        SC.build(parts, 24)
+
+
+@pytest.mark.gpu
+def test_code_volume_head_is_bit_identical_to_the_four_volume_head(K):
+    """From a subject's second sample on the head kernel reads its code volume (6 instead of 8 B/voxel): same volumes as with
+    the four label volumes, also after a seed volume was rewritten in place, and `invalidate_label_twins` drops the codes."""
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    for shape in ((64, 56, 72), (128, 128, 128)):
+        seg, seeds = make_seed_volumes(shape, 1)
+        kw = dict(nonlin_scale=(0.08, 0.2), bf_scale=(0.05, 0.2))
+        seg_d = torch.from_numpy(seg).to(DEV)
+        outs = {}
+        for use in (False, True):
+            gen = make_generator(shape, DEV, rng="keyed", **kw)
+            kc = gen.keyed_context(shape)
+            kc.use_codes = use
+            bank = SeedBank(seeds, DEV)
+            res = []
+            for i in range(5):
+                res.append(gen._pipeline(None, seg_d, bank, {}, scale01=True, key=sharding.sample_key(5, i))[:2])
+            assert (getattr(bank, "_seed_codes", None) is not None) == use
+            if use:
+                assert bank._seed_codes[2] is not None and bank._seed_codes[2][1].shape[0] <= 2048
+            # a seed volume rewritten through torch: the codes follow (their build is keyed to the volumes' versions)
+            bank.vol[3][2].copy_(torch.roll(bank.vol[3][2], 5, 0))
+            for i in range(5, 9):
+                res.append(gen._pipeline(None, seg_d, bank, {}, scale01=True, key=sharding.sample_key(5, i))[:2])
+            gen.invalidate_label_twins()
+            assert getattr(bank, "_seed_codes", None) is None
+            res.append(gen._pipeline(None, seg_d, bank, {}, scale01=True, key=sharding.sample_key(5, 9))[:2])
+            outs[use] = res
+        for a, b in zip(outs[False], outs[True]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # the selection really changed between samples (otherwise the test would not see a wrong tuple column)
+        assert len({tuple(gen.keyed_context(shape).draws(sharding.sample_key(5, i)).subclusters[:4]) for i in range(9)}) > 3
+
+
+@pytest.mark.gpu
+def test_device_code_builder_is_exact(K):
+    """fsg_seed_codes_build (one pass, hash set of columns) against the torch formulation: the same partition of the voxels and
+    the same labels for every selection (the numbering of the codes is free); more columns than FSG_CODES_MAX -> no codes."""
+    from fetalsyngen_amd import seedcodes as SC
+
+    for shape, variant in (((40, 36, 28), 1), ((128, 128, 128), 2)):
+        parts = [p.to(DEV) for p in _phantom_parts(shape, variant)]
+        got = SC.build_device(parts, 25)
+        want = SC.build(parts, 25)
+        assert got is not None and got[1].shape == want[1].shape
+        assert (got[1][:, 24] == 0).all()
+        # same partition: the pair (device code, torch code) takes exactly ntuples distinct values
+        pair = got[0].reshape(-1).to(torch.int64) * 4096 + want[0].reshape(-1).to(torch.int64)
+        assert torch.unique(pair).numel() == want[1].shape[0]
+        rs = np.random.RandomState(7)
+        for _ in range(6):
+            ns = rs.randint(1, 7, 4)
+            sel = [4 * (ns[m] - 1) + m for m in range(4)]
+            assert torch.equal(SC.labels_of(*got, sel), SC.labels_of(*want, sel))
+    # 4 096 distinct columns
+    n = 1 << 16
+    a = (torch.arange(n, device=DEV) % 256).to(torch.uint8)
+    b = ((torch.arange(n, device=DEV) // 256) % 16).to(torch.uint8)
+    assert SC.build_device([a, b], 3) is None
+    # 2 048 exactly: usable
+    b2 = ((torch.arange(n, device=DEV) // 256) % 8).to(torch.uint8)
+    got = SC.build_device([a, b2], 3)
+    assert got is not None and got[1].shape[0] == 2048
+    assert torch.equal(SC.labels_of(*got, [0, 1, 2, 2]), ((a.to(torch.int64) + b2.to(torch.int64)) & 255).to(torch.uint8))

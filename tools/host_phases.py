@@ -80,7 +80,7 @@ for i in range(a.n):
     iv[10], iv[11], iv[12] = (ws["rows"].data_ptr() if ws["rows"] is not None else 0), ws["stride"], 1
     iv[13] = iv[14] = iv[15] = 0; iv[16:80] = ent[0]; iv[80] = iv[81] = 0; t = tickk("fill the int64 argument array", t)
     d = _lib.KeyedDraws()
-    rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, 82, C.byref(d), K._stream(torch.device(dev))); t = tickk("fsg_keyed_sample_run (C: draws + 8 launches)", t)
+    rc = kc.lib.fsg_keyed_sample_run(kc.handle, kc.ivp, len(kc.iv), C.byref(d), K._stream(torch.device(dev))); t = tickk("fsg_keyed_sample_run (C: draws + 8 launches)", t)
     prm = _keyed.params_of(d, block); t = tickk("params_of (synth_params dict)", t)
 torch.cuda.synchronize()
 print(f"keyed mode, per-sample host phases, us (n={a.n}, size={a.size})")
