@@ -440,15 +440,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       U.code_ms[c] = lab < G.ntab ? make_float2(G.mus[lab], G.sigmas[lab]) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    const uint32_t ng = (uint32_t)(G.n >> 2), nb = gridDim.x - (unsigned)(nrows + nfaces), step = nb * blockDim.x;
+    // ONE 16-byte load of eight codes per lane and trip, then a Philox block, four table look-ups and a 16-byte store per group
+    // of four.  It is the width of a wave's read request that this kernel follows, not its bytes: uint8 codes (subjects with
+    // <= 256 columns) in 4 / 8 / 16-byte loads ran at 35.1 / 33.0 / 38.3 us (the last with one trip per thread), uint16 codes in
+    // 8 / 16-byte loads at 31.6 / 30.8 (event intervals of the bench); the one-byte form was dropped.
+    const uint32_t nb = gridDim.x - (unsigned)(nrows + nfaces), step = nb * blockDim.x;
     const uint8_t* __restrict__ codes = G.l0;
-    for (uint32_t g = (uint32_t)b * blockDim.x + threadIdx.x; g < ng; g += step) {
-      const uint2 w = *reinterpret_cast<const uint2*>(codes + (size_t)(g << 3));  // four uint16 codes
+    auto draw4 = [&](uint32_t g, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
       const float4 r = fsg_randn4<true>(G.seed, G.stream_id, (uint64_t)g);
-      const float2 m0 = U.code_ms[w.x & 0xFFFFu], m1 = U.code_ms[w.x >> 16], m2 = U.code_ms[w.y & 0xFFFFu], m3 = U.code_ms[w.y >> 16];
-      *reinterpret_cast<float4*>(reinterpret_cast<char*>(G.out) + (size_t)(g << 4)) =
+      const float2 m0 = U.code_ms[c0], m1 = U.code_ms[c1], m2 = U.code_ms[c2], m3 = U.code_ms[c3];
+      *reinterpret_cast<float4*>(reinterpret_cast<char*>(G.out) + (size_t)g * 16u) =
           make_float4(fmaxf(m0.x + m0.y * r.x, 0.f), fmaxf(m1.x + m1.y * r.y, 0.f), fmaxf(m2.x + m2.y * r.z, 0.f),
                       fmaxf(m3.x + m3.y * r.w, 0.f));
+    };
+    {
+      const uint32_t nt = (uint32_t)(G.n >> 3);
+      for (uint32_t t = (uint32_t)b * blockDim.x + threadIdx.x; t < nt; t += step) {
+        const uint4 w = *reinterpret_cast<const uint4*>(codes + (size_t)t * 16u);
+        draw4(2 * t, w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
+        draw4(2 * t + 1, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16);
+      }
     }
     return;
   }
@@ -1646,7 +1657,7 @@ int fsg_sample_head_codes_f32(const uint16_t* codes, const uint8_t* tuples, int 
   for (int m = 0; m < 4; ++m)
     if (sel[m] < 0 || sel[m] >= stride) return FSG_E_BADARG;
   if (ntuples > FSG_CODES_MAX || n > ((size_t)1 << 30)) return FSG_E_TOOBIG;
-  if ((n & 3) || ((uintptr_t)codes & 7) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
+  if ((n & 7) || ((uintptr_t)codes & 15) || ((uintptr_t)out & 15)) return FSG_E_ALIGN;
   HeadGmm G{reinterpret_cast<const uint8_t*>(codes), tuples, nullptr, nullptr, n, mus, sigmas, ntab, nullptr, seed, stream_id, out,
             ntuples, stride, (uint32_t)sel[0] | ((uint32_t)sel[1] << 8) | ((uint32_t)sel[2] << 16) | ((uint32_t)sel[3] << 24)};
   return launch_sample_head(G, n, d, epi, rows, row_stride, mm3, stream);
@@ -1671,7 +1682,8 @@ static int launch_sample_head(const HeadGmm& G, size_t n, const fsg_deform* d, c
   int nfaces = (faces + 255) / 256;
   if (nfaces > 1024) nfaces = 1024;
   size_t ngmm = ((n + 3) / 4 + 255) / 256;
-  if (ngmm > 4096) ngmm = 4096;  // 4 groups per thread: 33.8 us (8 192: 34.8, 16 384: 39.0)
+  if (ngmm > 4096) ngmm = 4096;  // 4 groups per thread: 33.8 us (8 192: 34.8, 16 384: 39.0); codes mode, 2 x 8 voxels per thread: 30.5 us
+                                 // (1 024: 34.7, 2 048: 37.0, 8 192: 33.6)
   if (nrows > 1000000) return FSG_E_TOOBIG;
   hipLaunchKernelGGL(sample_head_kernel, dim3((unsigned)(nrows + nfaces + ngmm)), dim3(256), 0, fsg_stream(stream), G, D,
                      E, rows, row_stride, rows_gx > 0 ? rows_gx : 1, (int)nrows, nfaces, mm3);

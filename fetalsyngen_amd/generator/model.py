@@ -1004,7 +1004,7 @@ class FetalSynthGen:
             if self._blur_tick % self.blur_events_every == 0:
                 events = (kc.lib.fsg_event_create(), kc.lib.fsg_event_create())
         iv[80], iv[81] = events if events is not None else (0, 0)
-        iv[82], iv[83], iv[84], iv[85] = ent[3], ent[4], ent[5], ent[6]  # the subject's code volume (0: four label volumes)
+        iv[82:86] = ent[3:7]  # the subject's code volume (0: four label volumes)
         d = _lib.KeyedDraws()
         import ctypes as C
 

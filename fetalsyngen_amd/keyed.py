@@ -181,7 +181,7 @@ class KeyedContext:
                     zero = torch.zeros_like(parts[0]) if zero is None else zero
                     col = zero
                 dense.append(col)
-            built = seedcodes.build_device(dense, stride) if (parts[0].numel() % 4 == 0 and parts[0].numel() <= (1 << 30)) else None
+            built = seedcodes.build_device(dense, stride) if (parts[0].numel() % 8 == 0 and parts[0].numel() <= (1 << 30)) else None
             have = (ver, self.shape, built, stride)
             bank._seed_codes = have
         built = have[2]

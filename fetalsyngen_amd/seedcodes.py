@@ -46,7 +46,7 @@ def build_device(parts, stride: int):
 def build(parts, stride: int):
     """parts: uint8 device tensors of one shape, column j of a tuple row = parts[j]; stride > len(parts) (the last byte of a
     row stays 0: the column an absent meta label selects).  Returns (codes int16 of the volumes' shape, tuples uint8
-    (T, stride)) or None when the subject has more than CODES_MAX distinct columns."""
+    (T, stride)) or None when the subject has more than CODES_MAX distinct columns.  (The torch formulation: tests, CPU.)"""
     if not parts or stride <= len(parts) or stride > 256:
         raise ValueError("seed codes: need 0 < len(parts) < stride <= 256")
     shape = parts[0].shape

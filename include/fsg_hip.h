@@ -392,8 +392,10 @@ int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream
  * subject holds at the voxels with code c (built once per subject by the caller: the distinct columns of the stacked seed
  * volumes); sel[m] = the byte of a row that belongs to the volume selected for meta label m (a zero byte for an absent one).
  * label = (tuples[c][sel[0]] + .. + tuples[c][sel[3]]) & 255 -- what fsg_sample_head_f32 adds up voxel by voxel
- * (rand_gmm.py:91-99) -- so the output is bit-identical.  n % 4 == 0, n <= 2^30, ntuples <= FSG_CODES_MAX, Philox noise only;
- * otherwise FSG_E_ALIGN / FSG_E_TOOBIG and the caller uses fsg_sample_head_f32. */
+ * (rand_gmm.py:91-99) -- so the output is bit-identical.  n % 8 == 0, n <= 2^30, ntuples <= FSG_CODES_MAX, Philox noise only;
+ * otherwise FSG_E_ALIGN / FSG_E_TOOBIG and the caller uses fsg_sample_head_f32.  (One-byte codes for subjects with <= 256
+ * columns were measured and dropped: the kernel follows the width of a wave's read request, not its bytes -- 35.1 / 33.0 / 38.3 us
+ * with 4 / 8 / 16-byte loads of uint8 codes against 31.6 / 30.8 with 8 / 16-byte loads of uint16 codes.) */
 #define FSG_CODES_MAX 2048
 int fsg_sample_head_codes_f32(const uint16_t* codes, const uint8_t* tuples, int ntuples, int stride, const int32_t sel[4],
                               size_t n, const float* mus, const float* sigmas, int ntab, uint64_t seed, uint64_t stream_id,

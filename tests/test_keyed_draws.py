@@ -366,7 +366,7 @@ def test_code_volume_head_is_bit_identical_to_the_four_volume_head(K):
                 res.append(gen._pipeline(None, seg_d, bank, {}, scale01=True, key=sharding.sample_key(5, i))[:2])
             assert (getattr(bank, "_seed_codes", None) is not None) == use
             if use:
-                assert bank._seed_codes[2] is not None and bank._seed_codes[2][1].shape[0] <= 2048
+                assert bank._seed_codes[2] is not None and bank._seed_codes[2][1].shape[0] <= 256
             # a seed volume rewritten through torch: the codes follow (their build is keyed to the volumes' versions)
             bank.vol[3][2].copy_(torch.roll(bank.vol[3][2], 5, 0))
             for i in range(5, 9):
