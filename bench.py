@@ -231,7 +231,8 @@ def stage_rooflines(traces, nvox):
         m0 = meta["low_shape"][0] if meta.get("low_shape") else meta["shape"][0]
         return {
             "upload": 65536.0, "draw": 65536.0,
-            "head": 8.0 * N,               # 4 x uint8 seed volumes read + float32 image written (K1; rows / face minima ~0)
+            # seed labels read (the subject's uint16 code volume, or 4 x uint8 volumes) + float32 image written (K1; rows / face minima ~0)
+            "head": (4.0 + meta.get("label_bytes", 4)) * N,
             "gmm": 8.0 * N,
             "floormin": 0.0,               # reads the coarse grid only
             "rows": 0.0,
@@ -712,7 +713,7 @@ def run(args, rank, world, local):
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: single {args.size}^3 label volume per step, full path, all gates on",
-                   "rng": args.rng, "inputs": "uint8 seed labels + fp32 segmentation (and its cached uint8 copy, which the label gather reads) resident in HBM",
+                   "rng": args.rng, "inputs": "uint8 seed labels (and the uint16 code volume built from them, which the GMM draw reads) + fp32 segmentation (and its cached uint8 copy, which the label gather reads) resident in HBM",
                    "outputs": "fp32 [0,1] image + fp32 labels in HBM", "volumes_per_rank": args.steps,
                    "parallelism": f"{world} independent replicas (no collective)", "streams_per_gpu": args.streams,
                    **({"tuning_flags": args.tune} if args.tune else {})},

@@ -1021,7 +1021,7 @@ class FetalSynthGen:
         _lib.check(rc, "fsg_keyed_sample_run")
         if tr is not None:
             tr.meta = {"shape": shape, "low_shape": tuple(d.low_shape) if d.resample_active else None,
-                       "blur_ntaps": list(d.blur_ntaps)}
+                       "blur_ntaps": list(d.blur_ntaps), "label_bytes": 2 if ent[3] else 4}
             self.stage_traces.append(tr)
         if not d.deform_active:  # no warp ran: the labels pass through
             if given:
