@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--stream-volumes", type=int, default=2000, help="config5: volumes streamed per rank and mode")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the samples are spread over (round robin)")
     ap.add_argument("--tune", type=int, default=0, help="fsg_set_tuning flags (A/B runs, e.g. 16384 = unfused blur + K7)")
+    ap.add_argument("--no-look-ahead", dest="look_ahead", action="store_false",
+                    help="keyed mode: do not name the next sample (its draw job then runs as a launch of its own)")
     ap.add_argument("--dry-plan", action="store_true", help="host plans only, no GPU (launcher test / host-cost probe)")
     return ap.parse_args(argv)
 
@@ -557,7 +559,10 @@ def run(args, rank, world, local):
         k = i % 4
         st = streams[i % len(streams)]
         if st is None:
-            out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True, key=key)
+            # a stream of samples knows what comes next: sample i + 1's draw job rides in sample i's floor(min) launch
+            # (fsg_keyed_sample_run's look-ahead; --no-look-ahead switches it off)
+            nxt = sharding.sample_key(1234, rank + world * (i + 1)) if keyed and args.look_ahead else None
+            out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True, key=key, next_key=nxt)
         else:
             with torch.cuda.stream(st):
                 out, seg_d, _img, p = gen._pipeline(None, base_segs[k], base_banks[k], {}, scale01=True, key=key)

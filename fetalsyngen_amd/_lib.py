@@ -110,6 +110,9 @@ class SamplePlan(C.Structure):
         ("code_ntuples", C.c_int32),
         ("code_stride", C.c_int32),
         ("code_sel", C.c_int32 * 4),
+        ("ride_draw", C.c_void_p),
+        ("ride_draw_blocks", C.c_uint32),
+        ("rode", C.c_void_p),
     ]
 
 
@@ -144,6 +147,7 @@ class KeyedDraws(C.Structure):
         ("noise_active", C.c_int32), ("noise_std", C.c_double), ("noise_std32", C.c_float),
         ("off_mm8", C.c_int32), ("off_slots", C.c_int32), ("off_mus", C.c_int32), ("off_sigmas", C.c_int32),
         ("off_bias", C.c_int32), ("off_field", C.c_int32), ("block_bytes", C.c_int32),
+        ("rode", C.c_int32),
     ]
 
 
@@ -151,7 +155,7 @@ E_NOTABLE = -4
 KT_RESAMPLE, KT_BACK, KT_FIELD, KT_BIAS = 0, 1, 2, 3
 KEYED_I = dict(KEY=0, OUT=1, SEG_OUT=2, SEG_OUT_U8=3, SEG_IN=4, SEG_IN_U8=5, BLOCK=6, WS0=7, WS1=8, WS_LOW=9, WS_ROWS=10,
                ROW_STRIDE=11, SCALE01=12, TRACE_EVENTS=13, TRACE_IDS=14, TRACE_CAP=15, BANK=16, EV_BLUR_BEGIN=80,
-               EV_BLUR_END=81, CODES=82, CODE_TUPLES=83, CODE_NTUPLES=84, CODE_STRIDE=85, COUNT=86)
+               EV_BLUR_END=81, CODES=82, CODE_TUPLES=83, CODE_NTUPLES=84, CODE_STRIDE=85, FLAGS=86, NEXT_KEY=87, NEXT_BLOCK=88, COUNT=89)
 
 STAGE_NAMES = ("begin", "upload", "draw", "head", "floormin", "warp", "blur_x", "blur_y", "blur_z", "blur_yz", "k7", "k9a", "k9b",
                "gmm", "rows", "pointwise", "blur_rs_x", "blur_rs_yz")  # include/fsg_hip.h: FSG_ST_*

@@ -9,6 +9,7 @@
 // The 192 MiB coordinate volumes and the 192 MiB up-sampled field of the reference are never
 // materialised: each thread re-evaluates the coarse field (<= 40 KB, L1/L2 resident) at its voxel.
 #include "fsg_common.h"
+#include "fsg_ride.h"
 
 int g_tuning_flags = 0;  // FSG_TUNE_* bits, see fsg_set_tuning
 int g_warp_variant = 0;   // fsg_warp_set_variant
@@ -431,36 +432,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     return;
   }
   b -= nrows;
-  if (G.ntuples > 0) {
-    // codes mode: (mu, sigma) of every code of the subject under this sample's selection, then 2 + 4 bytes per voxel
-    const uint8_t* __restrict__ tup = G.l1;
-    for (int c = threadIdx.x; c < G.ntuples; c += blockDim.x) {
-      const uint8_t* row = tup + (size_t)c * G.stride;
-      const int lab = (row[G.sel & 255u] + row[(G.sel >> 8) & 255u] + row[(G.sel >> 16) & 255u] + row[G.sel >> 24]) & 255;
-      U.code_ms[c] = lab < G.ntab ? make_float2(G.mus[lab], G.sigmas[lab]) : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    // ONE 16-byte load of eight codes per lane and trip, then a Philox block, four table look-ups and a 16-byte store per group
-    // of four.  It is the width of a wave's read request that this kernel follows, not its bytes: uint8 codes (subjects with
-    // <= 256 columns) in 4 / 8 / 16-byte loads ran at 35.1 / 33.0 / 38.3 us (the last with one trip per thread), uint16 codes in
-    // 8 / 16-byte loads at 31.6 / 30.8 (event intervals of the bench); the one-byte form was dropped.
-    const uint32_t nb = gridDim.x - (unsigned)(nrows + nfaces), step = nb * blockDim.x;
-    const uint8_t* __restrict__ codes = G.l0;
-    auto draw4 = [&](uint32_t g, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
-      const float4 r = fsg_randn4<true>(G.seed, G.stream_id, (uint64_t)g);
-      const float2 m0 = U.code_ms[c0], m1 = U.code_ms[c1], m2 = U.code_ms[c2], m3 = U.code_ms[c3];
-      *reinterpret_cast<float4*>(reinterpret_cast<char*>(G.out) + (size_t)g * 16u) =
-          make_float4(fmaxf(m0.x + m0.y * r.x, 0.f), fmaxf(m1.x + m1.y * r.y, 0.f), fmaxf(m2.x + m2.y * r.z, 0.f),
-                      fmaxf(m3.x + m3.y * r.w, 0.f));
-    };
-    {
-      const uint32_t nt = (uint32_t)(G.n >> 3);
-      for (uint32_t t = (uint32_t)b * blockDim.x + threadIdx.x; t < nt; t += step) {
-        const uint4 w = *reinterpret_cast<const uint4*>(codes + (size_t)t * 16u);
-        draw4(2 * t, w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
-        draw4(2 * t + 1, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16);
-      }
-    }
+  if (G.ntuples > 0) {  // codes mode (fsg_ride.h)
+    const fsg_ride::GmmCodesK C{G.l0, G.l1, G.ntuples, G.stride, G.sel, G.n, G.mus, G.sigmas, G.ntab, G.seed, G.stream_id, G.out};
+    fsg_ride::gmm_codes_job(C, U.code_ms, (unsigned)b, gridDim.x - (unsigned)(nrows + nfaces));
     return;
   }
   for (int t = threadIdx.x; t < 256; t += blockDim.x) {
@@ -948,8 +922,25 @@ __global__ __launch_bounds__(1024, 8) void warp_tile_kernel(FsgDeformK D, const 
 }
 
 template <bool MIN_ONLY>
+__device__ __forceinline__ void coords_minmax_rows_body(const FsgDeformK& D, int32_t* __restrict__ mm6, int rows_per_block, int blk);
+
+template <bool MIN_ONLY>
 __global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, int32_t* __restrict__ mm6,
                                                                  int rows_per_block) {
+  coords_minmax_rows_body<MIN_ONLY>(D, mm6, rows_per_block, (int)blockIdx.x);
+}
+
+// The conditional floor(min) pass with the NEXT sample's keyed draw job beside it (fsg_sample_plan::ride_draw): both are a few
+// workgroups of latency, and as launches of their own each costs ~5 us of the step.  Workgroups [0, nrest): the pass;
+// [nrest, nrest + draw workgroups): the draw (fsg_ride.h), which touches nothing of this sample.
+__global__ __launch_bounds__(256) void floormin_ride_kernel(FsgDeformK D, int32_t* __restrict__ mm6, int rows_per_block, int nrest,
+                                                            const fsg_ride::DrawK P) {
+  if ((int)blockIdx.x < nrest) coords_minmax_rows_body<true>(D, mm6, rows_per_block, (int)blockIdx.x);
+  else fsg_ride::keyed_draw_body(P, (int)blockIdx.x - nrest);
+}
+
+template <bool MIN_ONLY>
+__device__ __forceinline__ void coords_minmax_rows_body(const FsgDeformK& D, int32_t* __restrict__ mm6, int rows_per_block, int blk) {
   if (MIN_ONLY) {  // floor(min) already known to be 0 on every axis: nothing to add (block-uniform exit)
     const int32_t one = fsg_f2key(1.0f);
     const int32_t k0 = __hip_atomic_load(&mm6[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -963,7 +954,7 @@ __global__ __launch_bounds__(256) void coords_minmax_rows_kernel(FsgDeformK D, i
   float* sm = sm_all[wave];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   const int rows = D.n0 * D.n1;
-  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_begin = blk * rows_per_block;
   const int r_end = min(rows, r_begin + rows_per_block);
   const fsg_tap none = fsg_tap{0, 0, 0.f, 0.f};
   const bool cached = D.n2 <= 256;
@@ -1636,6 +1627,23 @@ int fsg_coords_floormin_rest_f32(const fsg_deform* d, int32_t* mm3, void* stream
 
 static int launch_sample_head(const HeadGmm& G, size_t n, const fsg_deform* d, const fsg_epilogue* epi, float* rows,
                               int row_stride, int32_t* mm3, void* stream);
+
+// ---- internal entry points of the look-ahead (fsg_pipeline.cpp; not part of include/fsg_hip.h) ------------------------------
+// the conditional floor(min) pass + the next sample's draw job (drawk: a fsg_ride::DrawK on the host)
+extern "C" int fsg_internal_floormin_rest_ride(const fsg_deform* d, int32_t* mm3, const void* drawk, unsigned draw_blocks, void* stream) {
+  FsgDeformK D;
+  int rc = fsg_fill_deform(d, D);
+  if (rc) return rc;
+  if (!mm3 || !drawk || draw_blocks == 0 || draw_blocks > 4096) return FSG_E_BADARG;
+  if ((D.field ? 3 * D.f2 : 0) > ROWCAP) return FSG_E_TOOBIG;
+  const int rows = D.n0 * D.n1;
+  int grid = (rows + 7) / 8 < 512 ? (rows + 7) / 8 : 512;
+  const int rpb = (rows + grid - 1) / grid;
+  grid = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(floormin_ride_kernel, dim3((unsigned)grid + draw_blocks), dim3(256), 0, fsg_stream(stream), D, mm3, rpb, grid,
+                     *reinterpret_cast<const fsg_ride::DrawK*>(drawk));
+  FSG_RETURN_LAUNCH();
+}
 
 int fsg_sample_head_f32(const uint8_t* l0, const uint8_t* l1, const uint8_t* l2, const uint8_t* l3, size_t n,
                         const float* mus, const float* sigmas, int ntab, const float* noise, uint64_t seed,

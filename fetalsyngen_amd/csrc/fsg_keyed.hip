@@ -19,11 +19,11 @@
 #include <cstring>
 #include <new>
 #include "fsg_common.h"
+#include "fsg_ride.h"
 
 namespace {
 
 constexpr int KT_CAP = 1024;  // largest grid size a table can be registered for
-#define FSG_MM_NSLOTS 64      // slots of the sharded K9 keys (generator/model.py: MM_NSLOTS; fsg_zoom3d_minmax_sharded_f32: 2..64)
 
 struct KeyedCtx {
   fsg_keyed_config cfg;
@@ -186,81 +186,14 @@ int draw(const KeyedCtx& C, uint64_t key, fsg_keyed_draws& d) {
 }
 
 // ---- the draw kernel -------------------------------------------------------------------------------------------------------
-// order-preserving keys of +inf / -inf (fsg_f2key): what fsg_minmax_init writes
-constexpr int32_t KEY_POS_INF = 0x7F800000, KEY_NEG_INF = (int32_t)0x807FFFFF;
+using fsg_ride::DrawK;
 
-struct DrawK {
-  uint64_t key;
-  int32_t* mm8;
-  int32_t* slots;
-  float* mus;
-  float* sigmas;
-  float* bias;
-  float* field;
-  int nlabels, nseed, tie, nbias, nfield;
-  float bias_std, field_std;
-  uint8_t seed_labels[256];
-  uint8_t gen_classes[256];
-};
+__global__ __launch_bounds__(256) void keyed_draw_kernel(const DrawK P) { fsg_ride::keyed_draw_body(P, (int)blockIdx.x); }
 
-__device__ __forceinline__ float keyed_uniform(uint64_t key, uint64_t stream, uint32_t e) {
-  const uint32_t blk = e >> 2;
-  const uint4 r = fsg_philox4x32_10(blk, 0u, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)key, (uint32_t)(key >> 32));
-  const uint32_t w = (e & 3) == 0 ? r.x : ((e & 3) == 1 ? r.y : ((e & 3) == 2 ? r.z : r.w));
-  return (float)(w >> 8) * 5.9604644775390625e-08f;  // [0, 1), 24 bits: torch.rand's float32 grid
-}
-
-// Workgroup 0: min/max keys, GMM tables (rand_gmm.py:120-145).  Workgroups >= 1: one Philox block (4 normals) per thread of
-// the bias grid (stream 4, synthseg.py:172-176) and the coarse displacement grid (stream 3, affine_nonrigid.py:318).
-__global__ __launch_bounds__(256) void keyed_draw_kernel(const DrawK P) {
-  const int tid = threadIdx.x;
-  if (blockIdx.x == 0) {
-    if (tid < 8) P.mm8[tid] = tid < 4 ? KEY_POS_INF : KEY_NEG_INF;
-    for (int q = tid; q < FSG_MM_NSLOTS * FSG_MM_SLOT_STRIDE; q += 256) {
-      const int f = q % FSG_MM_SLOT_STRIDE;
-      P.slots[q] = f == 0 ? KEY_POS_INF : (f == 1 ? KEY_NEG_INF : 0);
-    }
-    __shared__ float s_mu[256];
-    float sg = 0.f;
-    if (tid < P.nlabels) {
-      s_mu[tid] = 25.f + 200.f * keyed_uniform(P.key, 5, (uint32_t)tid);
-      sg = 5.f + 20.f * keyed_uniform(P.key, 5, (uint32_t)(P.nlabels + tid));
-    }
-    __syncthreads();
-    float tied = 0.f;
-    if (P.tie && tid < P.nseed) {  // the right-hand side is read in full before anything is written (numpy semantics)
-      tied = s_mu[P.gen_classes[tid]] + 25.f * fsg_randn1(P.key, 6, (uint64_t)tid);
-      tied = fminf(fmaxf(tied, 0.f), 225.f);
-    }
-    __syncthreads();
-    if (P.tie && tid < P.nseed) s_mu[P.seed_labels[tid]] = tied;
-    __syncthreads();
-    if (tid < P.nlabels) {
-      P.mus[tid] = s_mu[tid];
-      P.sigmas[tid] = sg;
-    }
-    return;
-  }
-  const int t = (blockIdx.x - 1) * 256 + tid;
-  const int nb4 = (P.nbias + 3) >> 2, nf4 = (P.nfield + 3) >> 2;
-  if (t < nb4) {
-    const float4 z = fsg_randn4(P.key, 4, (uint64_t)t);
-    const float v[4] = {z.x, z.y, z.z, z.w};
-    for (int q = 0; q < 4; ++q)
-      if (4 * t + q < P.nbias) P.bias[4 * t + q] = P.bias_std * v[q];
-  } else if (t - nb4 < nf4) {
-    const int u = t - nb4;
-    const float4 z = fsg_randn4(P.key, 3, (uint64_t)u);
-    const float v[4] = {z.x, z.y, z.z, z.w};
-    for (int q = 0; q < 4; ++q)
-      if (4 * u + q < P.nfield) P.field[4 * u + q] = P.field_std * v[q];
-  }
-}
-
-int launch_draw(const KeyedCtx& C, const fsg_keyed_draws& d, void* block_dev, void* stream) {
+// the draw job's argument block and its number of workgroups
+int fill_draw(const KeyedCtx& C, const fsg_keyed_draws& d, void* block_dev, DrawK& P, unsigned& grid) {
   if (!block_dev || ((uintptr_t)block_dev & 15)) return FSG_E_BADARG;
   char* base = (char*)block_dev;
-  DrawK P;
   P.key = d.key;
   P.mm8 = (int32_t*)(base + d.off_mm8);
   P.slots = (int32_t*)(base + d.off_slots);
@@ -278,7 +211,15 @@ int launch_draw(const KeyedCtx& C, const fsg_keyed_draws& d, void* block_dev, vo
   std::memcpy(P.seed_labels, C.cfg.seed_labels, 256);
   std::memcpy(P.gen_classes, C.cfg.generation_classes, 256);
   const int work = ((P.nbias + 3) >> 2) + ((P.nfield + 3) >> 2);
-  const unsigned grid = 1u + (unsigned)((work + 255) / 256);
+  grid = 1u + (unsigned)((work + 255) / 256);
+  return 0;
+}
+
+int launch_draw(const KeyedCtx& C, const fsg_keyed_draws& d, void* block_dev, void* stream) {
+  DrawK P;
+  unsigned grid = 0;
+  const int rc = fill_draw(C, d, block_dev, P, grid);
+  if (rc) return rc;
   hipLaunchKernelGGL(keyed_draw_kernel, dim3(grid), dim3(256), 0, fsg_stream(stream), P);
   FSG_RETURN_LAUNCH();
 }
@@ -457,7 +398,26 @@ int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws*
   q.ev_blur_begin = (void*)(uintptr_t)iv[FSG_KEYED_I_EV_BLUR_BEGIN];
   q.ev_blur_end = (void*)(uintptr_t)iv[FSG_KEYED_I_EV_BLUR_END];
 
-  if (q.trace_events && q.trace_ids && q.trace_cap > 1) {  // stage trace: an event before the draw kernel, the next one behind it
+  // ---- look-ahead: the caller names the next sample of this stream; its draw job rides in this sample's floor(min) launch -----
+  const int64_t flags = iv[FSG_KEYED_I_FLAGS];
+  const bool draw_done = (flags & 1) != 0;  // this sample's block was filled beside the previous sample's floor(min) pass
+  DrawK next_draw;
+  int32_t rode = 0;
+  char* nbase = (char*)(uintptr_t)iv[FSG_KEYED_I_NEXT_BLOCK];
+  if (nbase && (flags & 4)) {
+    fsg_keyed_draws dn;
+    rc = draw(*K, (uint64_t)iv[FSG_KEYED_I_NEXT_KEY], dn);
+    if (rc) return rc;
+    if (dn.block_bytes > K->block_bytes) return FSG_E_TOOBIG;
+    unsigned grid = 0;
+    rc = fill_draw(*K, dn, nbase, next_draw, grid);
+    if (rc) return rc;
+    q.ride_draw = &next_draw;
+    q.ride_draw_blocks = grid;
+    q.rode = &rode;
+  }
+
+  if (!draw_done && q.trace_events && q.trace_ids && q.trace_cap > 1) {  // stage trace: an event before the draw kernel, the next one behind it
     hipError_t e = hipEventRecord((hipEvent_t)q.trace_events[0], fsg_stream(stream));
     if (e != hipSuccess) return (int)e;
     q.trace_ids[0] = FSG_ST_BEGIN;
@@ -465,9 +425,13 @@ int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws*
     q.trace_start = 1;
     q.trace_first_id = FSG_ST_DRAW;
   }
-  rc = launch_draw(*K, d, base, stream);
-  if (rc) return rc;
-  return fsg_sample_run(&q, stream);
+  if (!draw_done) {
+    rc = launch_draw(*K, d, base, stream);
+    if (rc) return rc;
+  }
+  rc = fsg_sample_run(&q, stream);
+  if (draws_out) draws_out->rode = rode;
+  return rc;
 }
 
 }  // extern "C"

@@ -13,6 +13,10 @@
 #include <utility>
 #include "../../include/fsg_hip.h"
 
+// look-ahead launches (fsg_deform.hip, fsg_zoom.hip): not part of the public header
+extern "C" int fsg_internal_floormin_rest_ride(const fsg_deform* d, int32_t* mm3, const void* drawk, unsigned draw_blocks, void* stream);
+
+
 extern int g_tuning_flags;
 
 // ---- head of sample n+1 beside the tail of sample n (fsg_sample_plan::overlap) ---------------------------------------
@@ -91,6 +95,8 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
   const size_t n = (size_t)n0 * n1 * n2;
   if (n > (size_t)0x7FFFFFFF) return FSG_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
+  int rode = 0;  // look-ahead jobs that really went out (fsg_sample_plan::rode)
+  if (p->rode) *p->rode = 0;
 
   // stage trace (measurement only): an event behind every launch, see fsg_sample_plan::trace_events
   int ntrace = p->trace_start > 0 ? p->trace_start : 0;
@@ -181,7 +187,12 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     if (head_done) {
       d.rows = p->ws_rows;
       d.row_stride = p->row_stride;
-      FSG_TRY(fsg_coords_floormin_rest_f32(&d, p->mm8, stream));
+      if (p->ride_draw && p->ride_draw_blocks) {  // + the next sample's draw job (fsg_sample_plan::ride_draw)
+        FSG_TRY(fsg_internal_floormin_rest_ride(&d, p->mm8, p->ride_draw, p->ride_draw_blocks, stream));
+        rode |= 1;
+      } else {
+        FSG_TRY(fsg_coords_floormin_rest_f32(&d, p->mm8, stream));
+      }
       FSG_TRY(mark(FSG_ST_FLOORMIN));
     } else {
       if (p->ws_rows && need > 0 && need <= p->row_stride) {
@@ -292,6 +303,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
       FSG_TRY(fsg_zoom3d_normalise_sharded_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out,
                                                n0, n1, n2, p->mm_slots, p->mm_nslots, p->scale01 ? 1 : 0, stream));
       FSG_TRY(mark(FSG_ST_K9B));
+      if (p->rode) *p->rode = rode;
       return 0;
     }
     FSG_TRY(fsg_zoom3d_minmax_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], n0, n1, n2,
@@ -300,6 +312,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     FSG_TRY(fsg_zoom3d_normalise_f32(p->ws_low, m0, m1, m2, p->back_tab[0], p->back_tab[1], p->back_tab[2], p->out, n0,
                                      n1, n2, p->mm8 + 3, p->scale01 ? 1 : 0, stream));
     FSG_TRY(mark(FSG_ST_K9B));
+    if (p->rode) *p->rode = rode;
     return 0;
   }
 
@@ -317,6 +330,7 @@ extern "C" int fsg_sample_run(const fsg_sample_plan* p, void* stream) {
     hipError_t e = hipMemcpyAsync(p->out, cur, n * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
   }
+  if (p->rode) *p->rode = rode;
   return 0;
 }
 

@@ -577,7 +577,8 @@ template <int EPI>
 #ifndef FSG_SLAB_WAVES
 #define FSG_SLAB_WAVES 1  // minimum waves per SIMD asked of the register allocator (tuning: tools/ab builds)
 #endif
-__global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
+__device__ __forceinline__ void zoom_slab_body(const ZoomK& Z, const EpiZ& E, const int TY, const int cap_floats, const unsigned bid,
+                                               const unsigned nbk) {
   // domain (checked by the launcher): sz <= 256 and dz <= 256 -- a lane owns source elements lane + 64 c (c < 4) in the
   // y stage and outputs 4 lane .. 4 lane + 3 in the z stage, everything unrolled
   extern __shared__ __attribute__((aligned(16))) float zt_smem[];
@@ -589,8 +590,8 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
   __shared__ float red[2][4];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int tiles_y = (Z.dy + TY - 1) / TY;
-  const int nb = gridDim.x;
-  const int tile = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous x slabs
+  const int nb = (int)nbk;
+  const int tile = (nb & 7) == 0 ? (int)(bid & 7) * (nb >> 3) + (int)(bid >> 3) : (int)bid;  // XCD-contiguous x slabs
   const int i = tile / tiles_y, jt = tile - i * tiles_y;
   const int j0 = jt * TY, nj = min(TY, Z.dy - j0);
   float lo = INFINITY, hi = -INFINITY;
@@ -795,6 +796,13 @@ __global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z,
     }
   }
 }
+
+template <int EPI>
+__global__ __launch_bounds__(256, FSG_SLAB_WAVES) void zoom_slab_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
+  zoom_slab_body<EPI>(Z, E, TY, cap_floats, blockIdx.x, gridDim.x);
+}
+
+
 
 // ---- wave variant (r03; opt-in, FSG_TUNE_WAVE_ZOOM: bit-identical, slower than the slab kernel -- see launch1) -----------
 // Four INDEPENDENT waves per workgroup, no barrier: a wave owns ZW_ROWS consecutive output rows of one x-plane.  It forms the
@@ -1017,7 +1025,8 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     }
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;
-      hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3((unsigned)(Z.dx * tiles_y)), dim3(256), (size_t)total * sizeof(float),
+      const unsigned ntiles = (unsigned)(Z.dx * tiles_y);
+      hipLaunchKernelGGL(zoom_slab_kernel<EPI>, dim3(ntiles), dim3(256), (size_t)total * sizeof(float),
                          fsg_stream(stream), Z, E, TY, (int)est);
       FSG_RETURN_LAUNCH();
     }

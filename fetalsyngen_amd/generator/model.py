@@ -152,7 +152,7 @@ class FetalSynthGen:
     # DataLoader pattern: `num_workers=2, multiprocessing_context="spawn"`, fetalsyngen/test_dl.py:17-24, docs/datasets.md:4-6)
     # carries none of it into the worker.
     _PROCESS_LOCAL = ("_ws", "_flat", "_twins", "_seen_parts", "_arena_next", "_rs_dt", "_batch_streams", "blur_events",
-                      "_blur_tick", "_keyed", "stage_traces")
+                      "_blur_tick", "_keyed", "stage_traces", "_pre")
 
     def __getstate__(self):
         state = {k: v for k, v in self.__dict__.items() if k not in self._PROCESS_LOCAL}
@@ -960,9 +960,13 @@ class FetalSynthGen:
                 and segmentation.dtype == torch.float32 and segmentation.is_contiguous()
                 and (segmentation_u8 is None or labels_u8) and not any(a is not None for a in self.artifacts.values()))
 
-    def _pipeline_keyed(self, segmentation, bank, key, scale01, labels_u8, out=None, seg_out=None):
+    def _pipeline_keyed(self, segmentation, bank, key, scale01, labels_u8, out=None, seg_out=None, next_key=None):
         """One keyed sample: pointers + key -> ONE native call (draws, the draw kernel, the launch sequence).  Returns
-        (image, labels, None, synth_params) or None when the sample is outside the fused kernels' domain."""
+        (image, labels, None, synth_params) or None when the sample is outside the fused kernels' domain.
+
+        next_key: the key of the sample the caller will ask for NEXT on this stream (a batch, a stream of indices): its draw job
+        then rides in this sample's floor(min) launch (fsg_keyed_sample_run's look-ahead) -- one launch less on the next sample's
+        critical path, the same volumes.  If the next call is for another key or stream, the carried block is simply not used."""
         from .. import keyed
 
         shape = tuple(segmentation.shape)
@@ -980,7 +984,19 @@ class FetalSynthGen:
             out = torch.empty(shape, dtype=torch.float32, device=dev)
         if seg_out is None:
             seg_out = torch.empty(shape, dtype=torch.uint8 if labels_u8 else torch.float32, device=dev)
-        block = torch.empty(kc.block_bytes, dtype=torch.uint8, device=dev)
+        # what the previous call carried for this one (see next_key): the parameter block of exactly this key, on this stream
+        flags, block = 0, None
+        pre = self.__dict__.pop("_pre", None)
+        stream_id = K._stream(dev).value
+        if pre is not None and pre[0] == key and pre[1] == stream_id and pre[2] is kc:
+            block, flags = pre[3], 1
+        if block is None:
+            block = torch.empty(kc.block_bytes, dtype=torch.uint8, device=dev)
+        nblock = None
+        if next_key is not None:
+            next_key &= 0xFFFFFFFFFFFFFFFF
+            nblock = torch.empty(kc.block_bytes, dtype=torch.uint8, device=dev)
+            flags |= 4
         iv = kc.iv
         iv[0] = key if key < (1 << 63) else key - (1 << 64)
         iv[1] = out.data_ptr()
@@ -1005,6 +1021,11 @@ class FetalSynthGen:
                 events = (kc.lib.fsg_event_create(), kc.lib.fsg_event_create())
         iv[80], iv[81] = events if events is not None else (0, 0)
         iv[82:86] = ent[3:7]  # the subject's code volume (0: four label volumes)
+        iv[86] = flags
+        if nblock is not None:
+            iv[87], iv[88] = (next_key if next_key < (1 << 63) else next_key - (1 << 64)), nblock.data_ptr()
+        else:
+            iv[87] = iv[88] = 0
         d = _lib.KeyedDraws()
         import ctypes as C
 
@@ -1019,9 +1040,11 @@ class FetalSynthGen:
         if rc in (_lib.E_ALIGN, _lib.E_TOOBIG):
             return None
         _lib.check(rc, "fsg_keyed_sample_run")
+        if nblock is not None and d.rode:
+            self._pre = (next_key, stream_id, kc, nblock)
         if tr is not None:
             tr.meta = {"shape": shape, "low_shape": tuple(d.low_shape) if d.resample_active else None,
-                       "blur_ntaps": list(d.blur_ntaps), "label_bytes": 2 if ent[3] else 4}
+                       "blur_ntaps": list(d.blur_ntaps), "label_bytes": 2 if ent[3] else 4, "draw_carried": flags & 1}
             self.stage_traces.append(tr)
         if not d.deform_active:  # no warp ran: the labels pass through
             if given:
@@ -1031,7 +1054,7 @@ class FetalSynthGen:
         return out, seg_out, None, keyed.params_of(d, block)
 
     def _pipeline(self, image, segmentation, seeds, genparams, scale01: bool, segmentation_u8=None, labels_u8: bool = False,
-                  key: int | None = None):
+                  key: int | None = None, next_key: int | None = None):
         """labels_u8: return the labels as uint8 (same values; written as such by the fused warp where the fused path runs,
         converted afterwards otherwise).  key (keyed mode): the sample's 64-bit key; None = the key announced by
         `sharding.seed_for_sample` / `announce_key`, else one drawn from numpy's global generator."""
@@ -1044,7 +1067,7 @@ class FetalSynthGen:
                 key = int(np.random.randint(0, 1 << 62)) << 1
             key &= 0xFFFFFFFFFFFFFFFF
             if self._keyed_applies(image, segmentation, seeds, genparams, segmentation_u8, labels_u8):
-                got = self._pipeline_keyed(segmentation, seeds, key, scale01, labels_u8)
+                got = self._pipeline_keyed(segmentation, seeds, key, scale01, labels_u8, next_key=next_key)
                 if got is not None:
                     return got
             # outside the keyed path's domain: a "device"-mode sample of the global generators seeded from the key

@@ -492,6 +492,13 @@ typedef struct fsg_sample_plan {
   const uint8_t* code_tuples;
   int32_t code_ntuples, code_stride;
   int32_t code_sel[4];
+  /* Look-ahead (ABI 3; set by fsg_keyed_sample_run when the caller names the next sample, zero otherwise): the keyed draw job
+   * of the NEXT sample -- it depends on nothing of this one -- goes out beside this sample's conditional floor(min) pass
+   * instead of as a launch of its own.  ride_draw: host pointer to a library-internal argument block, valid for the call.
+   * *rode (may be NULL) receives 1 when the job really went out. */
+  const void* ride_draw;
+  uint32_t ride_draw_blocks;
+  int32_t* rode;
 } fsg_sample_plan;
 enum {
   FSG_ST_BEGIN = 0, FSG_ST_UPLOAD = 1, FSG_ST_DRAW = 2, FSG_ST_HEAD = 3, FSG_ST_FLOORMIN = 4, FSG_ST_WARP = 5, FSG_ST_BLUR_X = 6,
@@ -603,6 +610,7 @@ typedef struct fsg_keyed_draws {
   float noise_std32;
   /* byte offsets into the sample's device parameter block of what the draw kernel writes there */
   int32_t off_mm8, off_slots, off_mus, off_sigmas, off_bias, off_field, block_bytes;
+  int32_t rode; /* fsg_keyed_sample_run: 1 when the draw job of the NEXT sample went out with this one (look-ahead) */
 } fsg_keyed_draws;
 
 enum { FSG_KT_RESAMPLE = 0, FSG_KT_BACK = 1, FSG_KT_FIELD = 2, FSG_KT_BIAS = 3 };
@@ -630,7 +638,13 @@ enum {
   /* optional code volume of the subject (0 = none): uint16 codes, uint8 tuples [ntuples][stride] whose byte
    * 4 * (n_sub - min_subclusters) + (mlabel - 1) is the value of seed volume (n_sub, mlabel) and whose byte stride - 1 is 0 */
   FSG_KEYED_I_CODES = 16 + 66, FSG_KEYED_I_CODE_TUPLES = 16 + 67, FSG_KEYED_I_CODE_NTUPLES = 16 + 68, FSG_KEYED_I_CODE_STRIDE = 16 + 69,
-  FSG_KEYED_I_COUNT = 16 + 70
+  /* look-ahead (optional).  FLAGS bit 0: the block of THIS sample is already filled (the previous call carried its draw job);
+   * bit 2: NEXT_KEY / NEXT_BLOCK name the sample the caller will run next on this stream -- its draw job then rides in this
+   * sample's floor(min) launch (fsg_keyed_draws::rode says whether it did: not when the deformation gate is off).  A caller that
+   * then runs something else simply does not set bit 0.  (r03: the next sample's GMM draw beside the zoom-back launches was built
+   * and measured too -- 224 -> 230-244 us per step, the two jobs slow each other down -- and removed.) */
+  FSG_KEYED_I_FLAGS = 16 + 70, FSG_KEYED_I_NEXT_KEY = 16 + 71, FSG_KEYED_I_NEXT_BLOCK = 16 + 72,
+  FSG_KEYED_I_COUNT = 16 + 73
 };
 int fsg_keyed_sample_run(void* ctx, const int64_t* iv, int niv, fsg_keyed_draws* draws_out, void* stream);
 /* The draw kernel alone (tests): fills the parameter block of `draws` at block_dev. */

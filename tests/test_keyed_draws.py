@@ -411,3 +411,45 @@ def test_device_code_builder_is_exact(K):
     got = SC.build_device([a, b2], 3)
     assert got is not None and got[1].shape[0] == 2048
     assert torch.equal(SC.labels_of(*got, [0, 1, 2, 2]), ((a.to(torch.int64) + b2.to(torch.int64)) & 255).to(torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob", [1.0, 0.6])
+def test_look_ahead_carries_the_next_samples_draw_without_changing_a_voxel(K, prob):
+    """fsg_keyed_sample_run's look-ahead: with the next key named, the next sample's draw job rides in this sample's floor(min)
+    launch.  Same volumes as without; a wrong announcement, no announcement, or a deformation gate that switches the carrying
+    launch off must all fall back to a draw launch of the sample's own."""
+    from fetalsyngen_amd import sharding
+    from fetalsyngen_amd.data.datasets import SeedBank
+    from fetalsyngen_amd.phantom import make_seed_volumes
+
+    shape = (64, 56, 72)
+    kw = dict(prob=prob, nonlin_scale=(0.08, 0.2), bf_scale=(0.05, 0.2))
+    subj = [make_seed_volumes(shape, v) for v in range(3)]
+    segs = [torch.from_numpy(s).to(DEV) for s, _ in subj]
+    keys = [sharding.sample_key(77, i) for i in range(14)]
+    which = [0, 1, 1, 2, 0, 0, 1, 2, 2, 2, 0, 1, 0, 2]
+
+    ref_gen = make_generator(shape, DEV, rng="keyed", **kw)
+    ref_banks = [SeedBank(b, DEV) for _s, b in subj]
+    ref = [ref_gen._pipeline(None, segs[w], ref_banks[w], {}, scale01=True, key=k)[:2] for k, w in zip(keys, which)]
+
+    gen = make_generator(shape, DEV, rng="keyed", **kw)
+    banks = [SeedBank(b, DEV) for _s, b in subj]
+    carried = []
+    for i, (k, w) in enumerate(zip(keys, which)):
+        nxt = keys[i + 1] if i + 1 < len(keys) else None
+        if i == 4:    # announce the wrong key
+            nxt ^= 1
+        elif i == 9:  # announce nothing
+            nxt = None
+        if i == 11:   # another sample between two announced ones
+            gen._pipeline(None, segs[0], banks[0], {}, scale01=True, key=12345)
+        out, seg_o, _img, params = gen._pipeline(None, segs[w], banks[w], {}, scale01=True, key=k, next_key=nxt)
+        assert torch.equal(out, ref[i][0]) and torch.equal(seg_o, ref[i][1]), f"sample {i}"
+        assert params["key"] == k
+        carried.append("_pre" in gen.__dict__)
+    if prob == 1.0:  # the deformation gate is on: the job rides whenever a next key was named
+        assert all(c for j, c in enumerate(carried[:-1]) if j != 9) and not carried[9], carried
+    else:
+        assert any(carried) and not all(c for j, c in enumerate(carried[:-1]) if j != 9), carried
