@@ -111,10 +111,14 @@ class PrefetchingStream:
     def __len__(self):
         return len(self.indices)
 
-    def _produce(self, i):
-        # keyed mode: the sample is a function of its key alone -- no re-seeding of the global generators
+    def _produce(self, i, i_next=None):
+        # keyed mode: the sample is a function of its key alone -- no re-seeding of the global generators; the stream knows the
+        # next index, whose draw job then rides in this sample's launches (FetalSynthGen._pipeline_keyed: next_key)
+        next_key = None
         if self.ds.generator._is_keyed():
             sharding.announce_key(self.base_seed, i)
+            if i_next is not None:
+                next_key = sharding.sample_key(self.base_seed, i_next)
         else:
             sharding.seed_for_sample(self.base_seed, i)
         idx = i % len(self.ds)
@@ -122,7 +126,8 @@ class PrefetchingStream:
         name = self.ds._sub_ses_idx(idx)
         seeds = self.ds._seeds_for(name, idx)
         # device-resident hand-over: the fused warp writes the uint8 labels itself (no float32 labels, no conversion pass)
-        out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True, labels_u8=self._labels_u8)
+        out, seg, _img, params = self.ds.generator._pipeline(None, segm, seeds, {}, scale01=True, labels_u8=self._labels_u8,
+                                                             next_key=next_key)
         return out, seg, name
 
     def _produce_batch(self, idxs):
@@ -184,14 +189,16 @@ class PrefetchingStream:
         if self.batch_size:
             yield from self._iter_batches()
             return
+        order = list(self.indices)
+        following = order[1:] + [None]
         if not self.to_host:
-            for i in self.indices:
-                out, seg, name = self._produce(i)
+            for i, i_next in zip(order, following):
+                out, seg, name = self._produce(i, i_next)
                 yield {"image": out.unsqueeze(0), "label": seg.unsqueeze(0), "name": name}
             return
         pending = deque()
-        for i in self.indices:
-            out, seg, name = self._produce(i)
+        for i, i_next in zip(order, following):
+            out, seg, name = self._produce(i, i_next)
             if self._stager is None:
                 self._stager = HostStager(tuple(out.shape), out.device, self.depth, self.label_dtype, self.keep,
                                           image_dtype=self.image_dtype)

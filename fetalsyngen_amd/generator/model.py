@@ -986,10 +986,10 @@ class FetalSynthGen:
             seg_out = torch.empty(shape, dtype=torch.uint8 if labels_u8 else torch.float32, device=dev)
         # what the previous call carried for this one (see next_key): the parameter block of exactly this key, on this stream
         flags, block = 0, None
-        pre = self.__dict__.pop("_pre", None)
         stream_id = K._stream(dev).value
-        if pre is not None and pre[0] == key and pre[1] == stream_id and pre[2] is kc:
-            block, flags = pre[3], 1
+        pre = self.__dict__.setdefault("_pre", {}).pop(stream_id, None)  # one carried block per launch stream
+        if pre is not None and pre[0] == key and pre[1] is kc:
+            block, flags = pre[2], 1
         if block is None:
             block = torch.empty(kc.block_bytes, dtype=torch.uint8, device=dev)
         nblock = None
@@ -1041,7 +1041,9 @@ class FetalSynthGen:
             return None
         _lib.check(rc, "fsg_keyed_sample_run")
         if nblock is not None and d.rode:
-            self._pre = (next_key, stream_id, kc, nblock)
+            if len(self._pre) > 8:
+                self._pre.clear()
+            self._pre[stream_id] = (next_key, kc, nblock)
         if tr is not None:
             tr.meta = {"shape": shape, "low_shape": tuple(d.low_shape) if d.resample_active else None,
                        "blur_ntaps": list(d.blur_ntaps), "label_bytes": 2 if ent[3] else 4, "draw_carried": flags & 1}
@@ -1234,9 +1236,9 @@ class FetalSynthGen:
                 side[q].wait_event(fork)
         params = []
         for b, ((_img, seg, seeds), key) in enumerate(zip(items, keys)):
-            with torch.cuda.stream(side[b % nstreams]):
+            with torch.cuda.stream(side[b % nstreams]):  # (the next sample of THIS stream: its draw job rides along)
                 got = self._pipeline_keyed(seg, seeds, key & 0xFFFFFFFFFFFFFFFF, scale01, labels_u8, out=out_all[b],
-                                           seg_out=seg_all[b])
+                                           seg_out=seg_all[b], next_key=keys[b + nstreams] if b + nstreams < B else None)
             if got is None:
                 return None
             params.append(got[3])

@@ -448,7 +448,7 @@ def test_look_ahead_carries_the_next_samples_draw_without_changing_a_voxel(K, pr
         out, seg_o, _img, params = gen._pipeline(None, segs[w], banks[w], {}, scale01=True, key=k, next_key=nxt)
         assert torch.equal(out, ref[i][0]) and torch.equal(seg_o, ref[i][1]), f"sample {i}"
         assert params["key"] == k
-        carried.append("_pre" in gen.__dict__)
+        carried.append(bool(gen.__dict__.get("_pre")))
     if prob == 1.0:  # the deformation gate is on: the job rides whenever a next key was named
         assert all(c for j, c in enumerate(carried[:-1]) if j != 9) and not carried[9], carried
     else:
