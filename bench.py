@@ -341,13 +341,17 @@ def config4_sr(device, size=384, reps=3):
     # plane / 3 mm thick: HIP-event time, pixel-taps/s (their unit of work: one PSF tap of one slice pixel = a 2x2x2 gather +
     # blend, or one scattered contribution) and the bytes they must move (the volume once + the slices once)
     from fetalsyngen_amd import kernels as K
-    from fetalsyngen_amd.generator.artifacts.svort import get_PSF, random_stack
+    from fetalsyngen_amd.generator.artifacts.svort import get_PSF, random_init_stack_transforms
 
     res, res_slice, thick, nsl = 0.5, 0.8, 3.0, 80
     ss = int(np.ceil(int(np.sqrt(3 * size ** 2 / 2.0) * res / res_slice) / 32.0) * 32)
     psf = get_PSF(res_ratio=(res_slice / res, res_slice / res, thick / res)).to(device)
     np.random.seed(0)
-    tr = random_stack(nsl, gap=size * res / nsl / res, max_angle=0.3).to(device)
+    # stack orientations as Scanner.scan draws them (uniformly random rotations, svort transform.py:178-188, :359-369): the
+    # figures below are means over four stacks -- the forward kernel's time depends on the orientation (4-39 ms by direct
+    # gathers, 11-18 ms from the LDS plate; chosen per slice, profiles/r03_i_slice_acq_forward.txt)
+    stacks4 = [random_init_stack_transforms(nsl, size * res / nsl / res, False, 0).matrix().to(device) for _ in range(4)]
+    tr = stacks4[0]
     vol = torch.rand(shape, device=device)
     rs_ = res_slice / res
     sl = K.slice_acq_forward(tr, vol, None, None, psf, (ss, ss), rs_)
@@ -364,13 +368,14 @@ def config4_sr(device, size=384, reps=3):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps_
 
-    fwd = timed(lambda: K.slice_acq_forward(tr, vol, None, None, psf, (ss, ss), rs_))
-    adj = timed(lambda: K.slice_acq_adjoint(tr, psf, sl, None, None, shape, rs_, interp_psf=True, equalize=True))
+    fwd = float(np.mean([timed(lambda t_=t_: K.slice_acq_forward(t_, vol, None, None, psf, (ss, ss), rs_)) for t_ in stacks4]))
+    adj = float(np.mean([timed(lambda t_=t_: K.slice_acq_adjoint(t_, psf, sl, None, None, shape, rs_, interp_psf=True, equalize=True))
+                         for t_ in stacks4]))
     byt = 4.0 * size ** 3 + 4.0 * npix
     out["kernels"] = {
         "problem": {"slices": [nsl, ss, ss], "psf": list(psf.shape), "psf_taps": ntap, "pixel_taps": npix * ntap},
-        "forward": {"kernel": "sa_forward_linear_fast_kernel", "ms": round(fwd, 3), "G_pixel_taps_per_s": round(npix * ntap / fwd / 1e6, 1),
-                    "algorithmic_bytes": int(byt), "GBps": round(byt / fwd / 1e6, 1), "bound": "L1/TA gather rate (4 wave-gathers per tap), not HBM"},
+        "forward": {"kernel": "sa_forward_linear_fast_kernel / sa_forward_plate_kernel (per slice, by orientation)", "ms": round(fwd, 3), "G_pixel_taps_per_s": round(npix * ntap / fwd / 1e6, 1),
+                    "algorithmic_bytes": int(byt), "GBps": round(byt / fwd / 1e6, 1), "bound": "direct gathers: L1/TA lines per wave-gather (grows with the z component of the slice's x axis); plate: instruction issue + LDS"},
         "adjoint": {"kernel": "sa_adjoint_nn_lds_kernel (+ equalize)", "ms": round(adj, 3), "G_pixel_taps_per_s": round(npix * ntap / adj / 1e6, 1),
                     "algorithmic_bytes": int(byt + 4.0 * size ** 3), "GBps": round((byt + 4.0 * size ** 3) / adj / 1e6, 1),
                     "bound": "two passes over the taps in LDS (ds_add pre-summation) + one global atomic per touched cell"}}

@@ -32,9 +32,16 @@ struct SaParams {
   int pd, ph, pw;
   int n, h, w;
   float res;
+  // forward, linear PSF: which slices a launch takes (per workgroup, from the slice's own transform): 0 all, 1 those whose
+  // in-plane x axis has |z component| <= SA_PLATE_Z (direct gathers), 2 the others (plate kernel)
+  int fwd_select;
 };
 
 constexpr int SA_TILE = 16;
+// Direct gathers cost 4.2 + 10 |T10| + 35 |T20| ms for the 80 x 320^2 x 441-tap stack of the bench (lanes run along the
+// slice's x axis: its z component spreads a wave's gather over z planes, 590 KB apart), the plate kernel 12-18 ms whatever the
+// orientation (profiles/r03_i_slice_acq_forward.txt): they cross at |T20| ~ 0.4.
+constexpr float SA_PLATE_Z = 0.4f;
 constexpr int SA_MAX_PSF = 4096;  // elements (16 KB of LDS)
 constexpr int SA_MAX_AXIS = 64;
 
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
   if (in >= P.n) return;
   const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
+  if (P.fwd_select == 1 && fabsf(T[8]) > SA_PLATE_Z) return;  // this slice is the plate kernel's (uniform)
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);  // [<= np] (ox, oy, oz, psf)
   __shared__ int ntaps_s;
@@ -294,6 +302,213 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
   const bool good = weight > 0.f;
   slices[idx] = good ? val / weight : 0.f;
   if (weights) weights[idx] = good ? weight : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward, interp_psf = false, no volume mask, the plate of the volume in LDS (r03; selected by default for this case).
+//
+// The kernel above is bound by the L1/TA gather path: four 8-byte wave-gathers per PSF tap, each charged per cache line its
+// pixels touch.  Here a wave owns a 4 x 4 pixel tile (a workgroup the same 16 x 16 tile: four tiles per wave, one after the
+// other) and its 64 lanes are 16 pixels x 4 tap phases: phase p walks taps p, p + 4, ... of the compacted list, so the four
+// lane groups read four neighbouring taps of the same 16 pixels.  The taps are walked in chunks of whole PSF planes; for a chunk
+// the wave copies the bounding box of everything its 16 pixels sample there -- the tile's pixel centres +- the chunk's rotated
+// tap extent, clipped to the volume -- into its own 8 KB of LDS with coalesced row loads, and the 2 x 2 x 2 corners come from
+// LDS.  As many consecutive planes as fit form a chunk; a plane that does not fit by itself takes the direct gathers of the
+// kernel above.  A small tile keeps the box of an OBLIQUE plate small (an 8 x 8 tile's box is 3 300-6 500 floats per plane,
+// mostly empty: profiles/r03_g_notes.txt); the price is the order of the sum over the taps -- four partial sums per pixel,
+// combined (p0 + p1) + (p2 + p3) -- i.e. fp32 rounding against the kernel above (the tests' tolerances, 1e-5 relative).
+// No workgroup barrier after the tap compaction.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SAP_CAP = 2048;  // floats of plate per wave
+
+__device__ __forceinline__ void sap_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float sap_uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+__global__ __launch_bounds__(256) void sa_forward_plate_kernel(SaParams P, const float* __restrict__ vol,
+                                                               float* __restrict__ slices, float* __restrict__ weights) {
+  extern __shared__ float smem[];
+  const int tiles_x = (P.w + SA_TILE - 1) / SA_TILE, tiles = tiles_x * ((P.h + SA_TILE - 1) / SA_TILE);
+  const int xcd = blockIdx.x & 7, mq = blockIdx.x >> 3;
+  const int in = (mq / tiles) * 8 + xcd, tile = mq % tiles;
+  if (in >= P.n) return;
+  const int bx = tile % tiles_x, by = tile / tiles_x;
+  const float* __restrict__ T = P.tr + (size_t)in * 12;
+  if (P.fwd_select == 2 && !(fabsf(T[8]) > SA_PLATE_Z)) return;  // this slice is the direct kernel's (uniform)
+  const int np = P.pd * P.ph * P.pw;
+  float4* taps = reinterpret_cast<float4*>(smem);              // [<= np] (ox, oy, oz, psf), raster order
+  int* pstart = reinterpret_cast<int*>(taps + np);             // [pd + 1] first compacted tap of every PSF plane
+  float* pext = reinterpret_cast<float*>(pstart + P.pd + 1);   // [pd][6] min / max rotated offset of the plane's tap rectangle
+  float* boxes = pext + 6 * P.pd;                              // [4 waves][SAP_CAP]
+  boxes = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(boxes) + 15) & ~(uintptr_t)15);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (tid < 64) {  // wave 0: raster-order compaction by ballot prefix (as sa_forward_linear_fast_kernel) + plane starts
+    int count = 0;
+    const int pp = P.ph * P.pw;
+    for (int base = 0; base < np; base += 64) {
+      const int e = base + tid;
+      const float pv = e < np ? P.psf[e] : 0.f;
+      const bool nz = pv != 0.f;
+      const unsigned long long bal = __ballot(nz);
+      const int before = count + __popcll(bal & ((1ull << tid) - 1ull));
+      const int kz = e / pp;
+      if (e < np && e - kz * pp == 0) pstart[kz] = before;
+      if (nz) {
+        const int kx = e % P.pw, ky = (e / P.pw) % P.ph;
+        const float fx = (float)(kx - P.pw / 2), fy = (float)(ky - P.ph / 2), fz = (float)(kz - P.pd / 2);
+        taps[before] = make_float4(T[0] * fx + T[1] * fy + T[2] * fz, T[4] * fx + T[5] * fy + T[6] * fz,
+                                   T[8] * fx + T[9] * fy + T[10] * fz, pv);
+      }
+      count += __popcll(bal);
+    }
+    if (tid == 0) pstart[P.pd] = count;
+    if (tid < P.pd) {  // a linear map takes its extremes over a rectangle at the corners
+      const float fz = (float)(tid - P.pd / 2);
+      const float x0 = (float)(-(P.pw / 2)), x1 = (float)(P.pw - 1 - P.pw / 2), y0 = (float)(-(P.ph / 2)), y1 = (float)(P.ph - 1 - P.ph / 2);
+      for (int a = 0; a < 3; ++a) {
+        const float c0 = T[4 * a] * x0 + T[4 * a + 1] * y0, c1 = T[4 * a] * x1 + T[4 * a + 1] * y0;
+        const float c2 = T[4 * a] * x0 + T[4 * a + 1] * y1, c3 = T[4 * a] * x1 + T[4 * a + 1] * y1;
+        const float zt = T[4 * a + 2] * fz;
+        pext[6 * tid + a] = fminf(fminf(c0, c1), fminf(c2, c3)) + zt - 0.01f;      // (margin: the rounding of the per-tap products)
+        pext[6 * tid + 3 + a] = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)) + zt + 0.01f;
+      }
+    }
+  }
+  __syncthreads();  // the only workgroup barrier
+  const int l = lane & 15, phase = lane >> 4;
+  const float hx = (float)(P.W - 1), hy = (float)(P.H - 1), hz = (float)(P.D - 1);
+  const float rad = 0.5f * sqrtf((float)(P.pw * P.pw + P.ph * P.ph + P.pd * P.pd)) + 1.f;
+  const int Sy = P.W, Sz = P.H * P.W;
+  float* box = boxes + (size_t)wave * SAP_CAP;
+  const float BIG = 3.0e38f;
+  for (int tt = 0; tt < 4; ++tt) {
+    const int t16 = wave * 4 + tt;
+    const int ix = bx * SA_TILE + (t16 & 3) * 4 + (l & 3), iy = by * SA_TILE + (t16 >> 2) * 4 + (l >> 2);
+    const bool inside = ix < P.w && iy < P.h;
+    const size_t idx = ((size_t)in * P.h + (inside ? iy : 0)) * P.w + (inside ? ix : 0);
+    bool live = inside && !(P.smask && !P.smask[idx]);
+    float xc, yc, zc;
+    sa_centre(P, T, ix, iy, xc, yc, zc);
+    if (xc < -rad || yc < -rad || zc < -rad || xc > hx + rad || yc > hy + rad || zc > hz + rad) live = false;
+    float val = 0.f, weight = 0.f;
+    if (__any(live)) {
+      const float cx0 = sap_uni(fsg_wave_min(live ? xc : BIG)), cx1 = sap_uni(fsg_wave_max(live ? xc : -BIG));
+      const float cy0 = sap_uni(fsg_wave_min(live ? yc : BIG)), cy1 = sap_uni(fsg_wave_max(live ? yc : -BIG));
+      const float cz0 = sap_uni(fsg_wave_min(live ? zc : BIG)), cz1 = sap_uni(fsg_wave_max(live ? zc : -BIG));
+      int kz = 0;
+      while (kz < P.pd) {
+        // ---- the longest run of planes [kz, kz1) whose plate fits ----
+        int kz1 = kz, X0 = 0, Y0 = 0, Z0 = 0, ex = 0, ey = 0, ez = 0, pitch = 16;
+        float o0 = BIG, o1 = BIG, o2 = BIG, o3 = -BIG, o4 = -BIG, o5 = -BIG;
+        for (int k = kz; k < P.pd; ++k) {
+          const float a0 = fminf(o0, sap_uni(pext[6 * k])), a1 = fminf(o1, sap_uni(pext[6 * k + 1])), a2 = fminf(o2, sap_uni(pext[6 * k + 2]));
+          const float b0 = fmaxf(o3, sap_uni(pext[6 * k + 3])), b1 = fmaxf(o4, sap_uni(pext[6 * k + 4])), b2 = fmaxf(o5, sap_uni(pext[6 * k + 5]));
+          // samples outside [0, h) contribute nothing: the plate is clipped to the volume
+          // (BOTH ends clamped into the volume: a tile whose samples all lie beyond a face keeps a one-voxel box inside it --
+          // its samples are rejected by the bounds test and never read the box)
+          const int tx0 = min(max((int)floorf(cx0 + a0), 0), P.W - 1), tx1 = min(max((int)floorf(cx1 + b0) + 1, 0), P.W - 1);
+          const int ty0 = min(max((int)floorf(cy0 + a1), 0), P.H - 1), ty1 = min(max((int)floorf(cy1 + b1) + 1, 0), P.H - 1);
+          const int tz0 = min(max((int)floorf(cz0 + a2), 0), P.D - 1), tz1 = min(max((int)floorf(cz1 + b2) + 1, 0), P.D - 1);
+          const int nx = max(tx1 - tx0 + 1, 1), ny = max(ty1 - ty0 + 1, 1), nz = max(tz1 - tz0 + 1, 1);
+          const int pt = nx <= 16 ? 16 : 32;
+          if (nx > 32 || pt * ny * nz > SAP_CAP) break;
+          o0 = a0; o1 = a1; o2 = a2; o3 = b0; o4 = b1; o5 = b2;
+          X0 = tx0; Y0 = ty0; Z0 = tz0; ex = nx; ey = ny; ez = nz; pitch = pt;
+          kz1 = k + 1;
+        }
+        const bool plate = kz1 > kz;  // uniform
+        if (!plate) kz1 = kz + 1;     // this plane by direct gathers
+        const int t_beg = __builtin_amdgcn_readfirstlane(pstart[kz]), t_end = __builtin_amdgcn_readfirstlane(pstart[kz1]);
+        if (plate && t_end > t_beg) {
+          // ---- copy the plate: 64 / pitch rows per wave-instruction, four instructions in flight ----
+          const int nrow = ey * ez, rpi = 64 / pitch, xl = lane & (pitch - 1), rsub = lane / pitch;
+          const float inv_ey = 1.0f / (float)ey;
+          const bool xin = xl < ex;
+          for (int r0 = 0; r0 < nrow; r0 += 4 * rpi) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = r0 + u * rpi + rsub;
+              const int rz = (int)(((float)r + 0.5f) * inv_ey), ry = r - rz * ey;
+              v[u] = (r < nrow && xin) ? vol[(size_t)(Z0 + rz) * Sz + (size_t)(Y0 + ry) * Sy + (X0 + xl)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = r0 + u * rpi + rsub;
+              if (r < nrow) box[r * pitch + xl] = v[u];
+            }
+          }
+          sap_wave_sync();
+        }
+        const int py = pitch, pz = pitch * ey, org = Z0 * pz + Y0 * py + X0;
+        for (int t = t_beg + phase; t < t_end; t += 8) {  // two taps of this phase per trip
+          float pvv[2], wxx[2], wyy[2], wzz[2];
+          const float* qq[2];
+          int qi[2];
+          bool anyin = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int tu = t + 4 * u;
+            const float4 tp = taps[min(tu, t_end - 1)];
+            const float x = xc + tp.x, y = yc + tp.y, z = zc + tp.z;
+            const bool ok = live && (tu < t_end) && !(x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz);
+            const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+            wxx[u] = x - xf; wyy[u] = y - yf; wzz[u] = z - zf;
+            pvv[u] = ok ? tp.w : 0.f;
+            const int xi = (int)xf, yi = (int)yf, zi = (int)zf;
+            qq[u] = ok ? vol + (zi * Sz + yi * Sy + xi) : vol;
+            qi[u] = ok ? zi * pz + yi * py + xi - org : 0;
+            anyin |= ok;
+          }
+          if (!__any(anyin)) continue;
+          sa_f2u p00[2], p10[2], p01[2], p11[2];
+          if (plate) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float* b = box + qi[u];
+              p00[u] = sa_f2u{b[0], b[1]};
+              p10[u] = sa_f2u{b[py], b[py + 1]};
+              p01[u] = sa_f2u{b[pz], b[pz + 1]};
+              p11[u] = sa_f2u{b[pz + py], b[pz + py + 1]};
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              p00[u] = *reinterpret_cast<const sa_f2u*>(qq[u]);
+              p10[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sy);
+              p01[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sz);
+              p11[u] = *reinterpret_cast<const sa_f2u*>(qq[u] + Sz + Sy);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float wx = wxx[u], wy = wyy[u], wz = wzz[u];
+            const float a00 = p00[u].x + wx * (p00[u].y - p00[u].x), a10 = p10[u].x + wx * (p10[u].y - p10[u].x);
+            const float a01 = p01[u].x + wx * (p01[u].y - p01[u].x), a11 = p11[u].x + wx * (p11[u].y - p11[u].x);
+            const float b0 = a00 + wy * (a10 - a00), b1 = a01 + wy * (a11 - a01);
+            val += pvv[u] * (b0 + wz * (b1 - b0));
+            weight += pvv[u];
+          }
+        }
+        if (plate && t_end > t_beg) sap_wave_sync();  // the next chunk's copy overwrites the plate
+        kz = kz1;
+      }
+    }
+    // the four phases of a pixel: (p0 + p1) + (p2 + p3)
+    val += __shfl_xor(val, 16, FSG_WAVE);
+    weight += __shfl_xor(weight, 16, FSG_WAVE);
+    val += __shfl_xor(val, 32, FSG_WAVE);
+    weight += __shfl_xor(weight, 32, FSG_WAVE);
+    if (inside && phase == 0) {
+      const bool good = weight > 0.f;
+      slices[idx] = good ? val / weight : 0.f;
+      if (weights) weights[idx] = good ? weight : 0.f;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -758,8 +973,22 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
       hipLaunchKernelGGL((sa_forward_kernel<false, false>), grid, block, lds, st, P, vol, slices, slices_weight);
     else {
       const unsigned tiles = grid.x * grid.y, groups = (unsigned)((n + 7) / 8);
-      hipLaunchKernelGGL(sa_forward_linear_fast_kernel, dim3(8u * tiles * groups), block,
-                         (size_t)pd * ph * pw * 4 * sizeof(float), st, P, vol, slices, slices_weight);
+      const size_t lds_p = (size_t)pd * ph * pw * 4 * sizeof(float) + (size_t)(pd + 1) * sizeof(int) + (size_t)6 * pd * sizeof(float) +
+                           16 + (size_t)4 * SAP_CAP * sizeof(float);
+      // (small PSFs: the plate kernel's per-tile set-up outweighs its taps -- 101 taps: 8.7-9.0 ms against 2.4-6.1 direct)
+      const bool only_direct = (g_tuning_flags & FSG_TUNE_SA_FWD_DIRECT) || lds_p > 64000 ||
+                               (pd * ph * pw < 400 && !(g_tuning_flags & FSG_TUNE_SA_FWD_PLATE));
+      const bool only_plate = !only_direct && (g_tuning_flags & FSG_TUNE_SA_FWD_PLATE);
+      // r03: two launches, every slice taken by exactly one of them according to its own orientation (a workgroup of the other
+      // launch leaves on its first instructions): direct gathers where the slice's x axis stays near the volume's x-y plane,
+      // the plate of the volume in LDS (4 x 4 pixel tiles x 4 tap phases per wave) elsewhere
+      P.fwd_select = only_direct || only_plate ? 0 : 1;
+      if (!only_plate)
+        hipLaunchKernelGGL(sa_forward_linear_fast_kernel, dim3(8u * tiles * groups), block,
+                           (size_t)pd * ph * pw * 4 * sizeof(float), st, P, vol, slices, slices_weight);
+      P.fwd_select = only_direct || only_plate ? 0 : 2;
+      if (!only_direct)
+        hipLaunchKernelGGL(sa_forward_plate_kernel, dim3(8u * tiles * groups), dim3(256), lds_p, st, P, vol, slices, slices_weight);
     }
   } else {
     if (vol_mask) hipLaunchKernelGGL((sa_forward_kernel<true, true>), grid, block, lds, st, P, vol, slices, slices_weight);

@@ -83,6 +83,8 @@ const char* fsg_error_string(int code);
 #define FSG_TUNE_SLAB_ZOOM 8192 /* the slab zoom kernel also for the noise epilogues (default there: tile kernel) */
 #define FSG_TUNE_NO_LEAN 4096  /* fused warp: the r01 patch kernel body instead of the lean body (fsg_warp_lean.hip) */
 #define FSG_TUNE_NO_SEED_CODES 65536 /* A/B: the one-launch head reads the four label volumes even when the plan carries a code volume */
+#define FSG_TUNE_SA_FWD_DIRECT 131072 /* slice-acquisition forward (linear PSF, no volume mask): direct global gathers for every slice */
+#define FSG_TUNE_SA_FWD_PLATE 262144  /* ... the LDS plate kernel for every slice (default: chosen per slice by its orientation) */
 #define FSG_TUNE_WAVE_ZOOM 32768 /* opt in: zooms without a noise draw through the wave kernel (independent waves; slower in r03) */
 #define FSG_TUNE_NO_BLUR_RS 16384 /* fsg_sample_run: blur x3 + K7 as separate launches instead of the fused blur+resample pair */
 #define FSG_TUNE_BRICK 16        /* opt in: uint8-label warps through the LDS brick kernel (experimental, slower in r01) */

@@ -186,3 +186,34 @@ def test_adjoint_lds_presum_matches_direct_atomics(K, tuning):
         assert float(refw.sum()) > 1000
         np.testing.assert_allclose(host(gotw), host(refw), rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(host(got), host(ref), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_forward_plate_kernel_equals_direct_gathers_for_any_orientation(K):
+    """r03: the forward model (linear PSF, no volume mask) runs per slice either by direct gathers or from a plate of the volume in
+    LDS (4 x 4 pixel tiles, the taps split over four lane groups: another order of the sum).  Uniformly random orientations
+    (what Scanner.scan draws, svort transform.py:178-188), slices reaching beyond every face of the volume, a slice mask:
+    plate-only, direct-only and the default per-slice choice agree to fp32 rounding."""
+    from fetalsyngen_amd import _lib
+    from fetalsyngen_amd.generator.artifacts.svort import get_PSF, random_init_stack_transforms
+
+    lib = _lib.load()
+    np.random.seed(3)
+    vs = (72, 64, 80)
+    vol = torch.rand(vs, device=DEV) * 100
+    for res_ratio, ss, rs in (((1.6, 1.6, 6.0), (64, 80), 1.6), ((1.0, 1.0, 3.0), (96, 96), 1.0)):
+        psf = get_PSF(res_ratio=res_ratio).to(DEV)
+        for rep in range(4):
+            tr = random_init_stack_transforms(12, 5.0, False, 6.0).matrix().to(DEV)
+            sm = (torch.rand((12, *ss), device=DEV) > 0.2) if rep == 3 else None
+            got = {}
+            for name, flag in (("direct", 131072), ("plate", 262144), ("auto", 0)):
+                lib.fsg_set_tuning(flag)
+                try:
+                    got[name] = K.slice_acq_forward(tr, vol, None, sm, psf, ss, rs, need_weight=True)
+                finally:
+                    lib.fsg_set_tuning(0)
+            for name in ("plate", "auto"):
+                np.testing.assert_allclose(host(got[name][0]), host(got["direct"][0]), rtol=2e-5, atol=2e-4)
+                np.testing.assert_allclose(host(got[name][1]), host(got["direct"][1]), rtol=2e-5, atol=1e-5)
+            assert float(got["direct"][1].max()) > 0  # the stack does meet the volume
