@@ -35,18 +35,24 @@ __device__ __forceinline__ int sc_global_code(const CodesK& P, const uint32_t* c
     const int st = __hip_atomic_load(&P.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if (st == 2) {
       bool same = true;
-      for (int w = 0; w < P.nwords; ++w)
-        same = same && __hip_atomic_load(&P.slot_col[(size_t)slot * SC_WORDS + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == col[w];
+#pragma unroll
+      for (int w = 0; w < SC_WORDS; ++w)
+        if (w < P.nwords)
+          same = same && __hip_atomic_load(&P.slot_col[(size_t)slot * SC_WORDS + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == col[w];
       if (same) return __hip_atomic_load(&P.slot_code[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       slot = (slot + 1) & (SC_SLOTS - 1);
     } else if (st == 0) {
       if (__hip_atomic_load(P.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > SC_SLOTS / 2) return -1;  // filling up: give up
       if (atomicCAS(&P.state[slot], 0, 1) == 0) {
         const int c = atomicAdd(P.count, 1);
-        for (int w = 0; w < P.nwords; ++w) __hip_atomic_store(&P.slot_col[(size_t)slot * SC_WORDS + w], col[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int w = 0; w < SC_WORDS; ++w)
+          if (w < P.nwords) __hip_atomic_store(&P.slot_col[(size_t)slot * SC_WORDS + w], col[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&P.slot_code[slot], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c < P.cap)
-          for (int j = 0; j < P.nparts; ++j) P.tuples[(size_t)c * P.stride + j] = (uint8_t)(col[j >> 2] >> (8 * (j & 3)));
+#pragma unroll
+          for (int j = 0; j < SC_MAXPARTS; ++j)
+            if (j < P.nparts) P.tuples[(size_t)c * P.stride + j] = (uint8_t)(col[j >> 2] >> (8 * (j & 3)));
         __hip_atomic_store(&P.state[slot], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return c;
       }
@@ -61,50 +67,76 @@ __device__ __forceinline__ int sc_global_code(const CodesK& P, const uint32_t* c
 // workgroup fence; a reader that meets anything but a published entry just takes the global path.
 constexpr int SC_LOCAL = 256;
 
+// resolve one column to its code: the workgroup's LDS cache first, the global hash set on a miss
+__device__ __forceinline__ int sc_resolve(const CodesK& P, const uint32_t* col, uint32_t (*l_col)[SC_WORDS], int* l_code) {
+  uint32_t h = 2166136261u;
+#pragma unroll
+  for (int w = 0; w < SC_WORDS; ++w) {
+    if (w < P.nwords) {
+      h = (h ^ col[w]) * 16777619u;
+      h ^= h >> 15;
+    }
+  }
+  uint32_t ls = (h >> 13) & (SC_LOCAL - 1);
+  int free_slot = -1;
+  for (int probe = 0; probe < 4; ++probe) {
+    const int lc = __hip_atomic_load(&l_code[ls], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lc >= 0) {
+      bool same = true;
+#pragma unroll
+      for (int w = 0; w < SC_WORDS; ++w)
+        if (w < P.nwords) same = same && l_col[ls][w] == col[w];
+      if (same) return lc;
+    } else if (lc == -1 && free_slot < 0) {
+      free_slot = (int)ls;
+    }
+    ls = (ls + 1) & (SC_LOCAL - 1);
+  }
+  const int code = sc_global_code(P, col, h);
+  if (code >= 0 && free_slot >= 0 && atomicCAS(&l_code[free_slot], -1, -2) == -1) {
+#pragma unroll
+    for (int w = 0; w < SC_WORDS; ++w)
+      if (w < P.nwords) l_col[free_slot][w] = col[w];
+    __hip_atomic_store(&l_code[free_slot], code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  return code;
+}
+
+// Four consecutive voxels per lane: one 4-byte load per seed volume (a wave's request is 256 bytes instead of 64), four
+// columns resolved one after the other, one 8-byte store of their codes.  n % 4 == 0 and 4-byte aligned volumes (the launcher
+// falls back to the one-voxel form otherwise).
+template <int VPL>
 __global__ __launch_bounds__(256) void seed_codes_kernel(const CodesK P) {
   __shared__ uint32_t l_col[SC_LOCAL][SC_WORDS];
   __shared__ int l_code[SC_LOCAL];
   for (int e = threadIdx.x; e < SC_LOCAL; e += 256) l_code[e] = -1;
   __syncthreads();
-  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < P.n; v += gridDim.x * 256u) {
-    uint32_t col[SC_WORDS];
+  const uint32_t ng = P.n / VPL;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < ng; g += gridDim.x * 256u) {
+    uint32_t col[VPL][SC_WORDS];
 #pragma unroll
-    for (int w = 0; w < SC_WORDS; ++w) col[w] = 0u;
-    uint32_t h = 2166136261u;
+    for (int q = 0; q < VPL; ++q)
 #pragma unroll
-    for (int w = 0; w < SC_WORDS; ++w) {
-      if (w < P.nwords) {  // uniform
+      for (int w = 0; w < SC_WORDS; ++w) col[q][w] = 0u;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int j = 4 * w + b;
-          if (j < P.nparts) col[w] |= (uint32_t)P.part[j][v] << (8 * b);
-        }
-        h = (h ^ col[w]) * 16777619u;
-        h ^= h >> 15;
+    for (int j = 0; j < SC_MAXPARTS; ++j) {
+      if (j < P.nparts) {  // uniform
+        uint32_t word;
+        if (VPL == 4) word = *reinterpret_cast<const uint32_t*>(P.part[j] + (size_t)g * 4u);
+        else word = P.part[j][g];
+#pragma unroll
+        for (int q = 0; q < VPL; ++q) col[q][j >> 2] |= ((word >> (8 * q)) & 255u) << (8 * (j & 3));
       }
     }
-    int code = -1;
-    uint32_t ls = (h >> 13) & (SC_LOCAL - 1);
-    int free_slot = -1;
-    for (int probe = 0; probe < 4 && code < 0; ++probe) {
-      const int lc = __hip_atomic_load(&l_code[ls], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (lc >= 0) {
-        bool same = true;
-        for (int w = 0; w < P.nwords; ++w) same = same && l_col[ls][w] == col[w];
-        if (same) code = lc;
-      } else if (lc == -1 && free_slot < 0) {
-        free_slot = (int)ls;
-      }
-      ls = (ls + 1) & (SC_LOCAL - 1);
+    uint32_t packed[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < VPL; ++q) {
+      const int code = sc_resolve(P, col[q], l_col, l_code);
+      const uint32_t c16 = (uint32_t)(code < 0 || code >= P.cap ? 0 : code);
+      packed[q >> 1] |= c16 << (16 * (q & 1));
     }
-    if (code < 0) {
-      code = sc_global_code(P, col, h);
-      if (code >= 0 && free_slot >= 0 && atomicCAS(&l_code[free_slot], -1, -2) == -1) {
-        for (int w = 0; w < P.nwords; ++w) l_col[free_slot][w] = col[w];
-        __hip_atomic_store(&l_code[free_slot], code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-    P.codes[v] = (uint16_t)(code < 0 || code >= P.cap ? 0 : code);
+    if (VPL == 4) *reinterpret_cast<uint2*>(P.codes + (size_t)g * 4u) = make_uint2(packed[0], packed[1]);
+    else P.codes[g] = (uint16_t)packed[0];
   }
 }
 
@@ -139,7 +171,15 @@ int fsg_seed_codes_build(const uint8_t* const* parts, int nparts, size_t n, int 
   P.count = count_dev;
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(seed_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P);
+  bool quad = (n & 3) == 0 && (((uintptr_t)codes) & 7) == 0;
+  for (int j = 0; j < nparts; ++j) quad = quad && (((uintptr_t)parts[j]) & 3) == 0;
+  if (quad) {
+    blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(seed_codes_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, P);
+  } else {
+    hipLaunchKernelGGL(seed_codes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, P);
+  }
   FSG_RETURN_LAUNCH();
 }
 

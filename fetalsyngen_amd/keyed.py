@@ -150,7 +150,7 @@ class KeyedContext:
                                      f"got {part.dtype} {tuple(part.shape)} on {part.device}")
                 ptrs[4 * (n - c.min_subclusters) + (m - 1)] = part.data_ptr()
         ent = [ptrs, 0 if twin is None else twin.data_ptr(), seg.data_ptr(), 0, 0, 0, 0]  # .. codes, tuples, ntuples, stride
-        self._codes(bank, ent)  # ~4 ms once per bank object (one pass over its volumes), little next to loading the subject
+        self._codes(bank, ent)  # ~1 ms once per bank object (one pass over its volumes), little next to loading the subject
         if len(self._subjects) > 4096:
             self._subjects.clear()
         self._subjects[key] = (weakref.ref(bank), weakref.ref(seg), seg._version, ent)

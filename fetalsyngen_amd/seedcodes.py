@@ -15,7 +15,7 @@ CODES_MAX = 2048  # FSG_CODES_MAX
 
 def build_device(parts, stride: int):
     """`build` for CUDA volumes through the library's one-pass kernel (`fsg_seed_codes_build`, csrc/fsg_codes.hip: an exact hash
-    set of columns): ~4 ms per 256^3 subject (40 ms for the torch formulation below with its 24 sorts).  Synchronises once (the number
+    set of columns): ~1 ms per 256^3 subject (40 ms for the torch formulation below with its 24 sorts).  Synchronises once (the number
     of distinct columns decides whether the codes are usable)."""
     import ctypes as C
 
