@@ -580,7 +580,7 @@ def run(args, rank, world, local):
     # the next dozen still run with cold interpreter / allocator / clock state (host 300-400 us per sample against 260 later:
     # gpurun_out r4m, tools/warmup_curve.py).  Like prewarm() and reserve() above this is one-off process start-up, so a short
     # --warmup measures the same steady state as a long one; reported as "setup_samples".
-    setup_samples = 0 if os.environ.get("FSG_BENCH_NO_SETUP_SAMPLES") else 24
+    setup_samples = 0 if os.environ.get("FSG_BENCH_NO_SETUP_SAMPLES") else int(os.environ.get("FSG_BENCH_SETUP_SAMPLES", "24"))
     for i in range(setup_samples):
         step(10_000_000 + i)
     torch.cuda.synchronize()
@@ -597,14 +597,24 @@ def run(args, rank, world, local):
     _drop_events(gen.blur_events)
     R.barrier()
     torch.cuda.synchronize()
+    edge = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if os.environ.get("FSG_BENCH_EDGES") else None
     t0 = time.perf_counter()
+    if edge:
+        edge[0].record()
     for i in range(args.steps):
         _o, _s, p = step(args.warmup + i)
         mus_seen.append(p["resample_params"]["spacing"])
+    if edge:
+        edge[1].record()
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
+    t_sync = time.perf_counter() - t0
     R.barrier()
     dt_rank = time.perf_counter() - t0
     dt = R.max(dt_rank)
+    if edge and rank == 0:  # diagnostic: where the timed region's fixed part goes (stderr, not part of the line)
+        print(json.dumps({"edges": {"wall_ms": round(dt_rank * 1e3, 3), "enqueue_done_ms": round(t_enq * 1e3, 3), "sync_done_ms": round(t_sync * 1e3, 3),
+                                    "gpu_span_ms": round(edge[0].elapsed_time(edge[1]), 3)}}), file=sys.stderr, flush=True)
 
     # ---- per-launch times of the same samples' kind, UNTIMED: HIP events behind every launch of 16 further samples ------------
     gen.blur_events_save, gen.blur_events = gen.blur_events, None
