@@ -32,16 +32,19 @@ struct SaParams {
   int pd, ph, pw;
   int n, h, w;
   float res;
-  // forward, linear PSF: which slices a launch takes (per workgroup, from the slice's own transform): 0 all, 1 those whose
-  // in-plane x axis has |z component| <= SA_PLATE_Z (direct gathers), 2 the others (plate kernel)
+  // forward, linear PSF: which slices a launch takes (per workgroup, from the slice's own transform): 0 all, 1 those with
+  // sa_direct_cost(T) <= fwd_thr (direct gathers), 2 the others (plate kernel)
   int fwd_select;
+  float fwd_thr;
 };
 
 constexpr int SA_TILE = 16;
-// Direct gathers cost 4.2 + 10 |T10| + 35 |T20| ms for the 80 x 320^2 x 441-tap stack of the bench (lanes run along the
-// slice's x axis: its z component spreads a wave's gather over z planes, 590 KB apart), the plate kernel 12-18 ms whatever the
-// orientation (profiles/r03_i_slice_acq_forward.txt): they cross at |T20| ~ 0.4.
-constexpr float SA_PLATE_Z = 0.4f;
+// Direct gathers cost 4.2 + ~10 |T10| + ~35 |T20| ms for the 80 x 320^2 x 441-tap stack of the bench (lanes run along the
+// slice's x axis: its y component spreads a wave's gather over rows, its z component over planes 590 KB apart), the plate
+// kernel 5.7 ms aligned, 6-9 ms for most orientations, up to 18 ms with the x axis along the volume's z
+// (profiles/r03_i_slice_acq_forward.txt): direct gathers only win for nearly aligned slices (and a little longer for small PSFs,
+// whose plate set-up weighs more).
+__device__ __forceinline__ float sa_direct_cost(const float* T) { return 10.f * fabsf(T[4]) + 35.f * fabsf(T[8]); }
 constexpr int SA_MAX_PSF = 4096;  // elements (16 KB of LDS)
 constexpr int SA_MAX_AXIS = 64;
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
   if (in >= P.n) return;
   const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
-  if (P.fwd_select == 1 && fabsf(T[8]) > SA_PLATE_Z) return;  // this slice is the plate kernel's (uniform)
+  if (P.fwd_select == 1 && sa_direct_cost(T) > P.fwd_thr) return;  // this slice is the plate kernel's (uniform)
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);  // [<= np] (ox, oy, oz, psf)
   __shared__ int ntaps_s;
@@ -337,13 +340,15 @@ __global__ __launch_bounds__(256) void sa_forward_plate_kernel(SaParams P, const
   if (in >= P.n) return;
   const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
-  if (P.fwd_select == 2 && !(fabsf(T[8]) > SA_PLATE_Z)) return;  // this slice is the direct kernel's (uniform)
+  if (P.fwd_select == 2 && !(sa_direct_cost(T) > P.fwd_thr)) return;  // this slice is the direct kernel's (uniform)
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);              // [<= np] (ox, oy, oz, psf), raster order
   int* pstart = reinterpret_cast<int*>(taps + np);             // [pd + 1] first compacted tap of every PSF plane
   float* pext = reinterpret_cast<float*>(pstart + P.pd + 1);   // [pd][6] min / max rotated offset of the plane's tap rectangle
-  float* boxes = pext + 6 * P.pd;                              // [4 waves][SAP_CAP]
-  boxes = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(boxes) + 15) & ~(uintptr_t)15);
+  // [4 waves][SAP_CAP], 16-byte aligned.  (As an OFFSET into smem: rounding the pointer up through uintptr_t makes it a generic
+  // pointer, and every access to the plate went out as a flat load / store through the vector-memory path -- 150 M vector-memory
+  // reads per launch, more than the direct kernel's gathers: profiles/r03_i_slice_acq_forward.txt.)
+  float* boxes = smem + ((4 * np + (P.pd + 1) + 6 * P.pd + 3) & ~3);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (tid < 64) {  // wave 0: raster-order compaction by ballot prefix (as sa_forward_linear_fast_kernel) + plane starts
@@ -975,13 +980,12 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
       const unsigned tiles = grid.x * grid.y, groups = (unsigned)((n + 7) / 8);
       const size_t lds_p = (size_t)pd * ph * pw * 4 * sizeof(float) + (size_t)(pd + 1) * sizeof(int) + (size_t)6 * pd * sizeof(float) +
                            16 + (size_t)4 * SAP_CAP * sizeof(float);
-      // (small PSFs: the plate kernel's per-tile set-up outweighs its taps -- 101 taps: 8.7-9.0 ms against 2.4-6.1 direct)
-      const bool only_direct = (g_tuning_flags & FSG_TUNE_SA_FWD_DIRECT) || lds_p > 64000 ||
-                               (pd * ph * pw < 400 && !(g_tuning_flags & FSG_TUNE_SA_FWD_PLATE));
+      const bool only_direct = (g_tuning_flags & FSG_TUNE_SA_FWD_DIRECT) || lds_p > 64000;
       const bool only_plate = !only_direct && (g_tuning_flags & FSG_TUNE_SA_FWD_PLATE);
       // r03: two launches, every slice taken by exactly one of them according to its own orientation (a workgroup of the other
       // launch leaves on its first instructions): direct gathers where the slice's x axis stays near the volume's x-y plane,
       // the plate of the volume in LDS (4 x 4 pixel tiles x 4 tap phases per wave) elsewhere
+      P.fwd_thr = pd * ph * pw < 400 ? 8.0f : 1.7f;  // measured crossovers (101 / 441 / 697 taps)
       P.fwd_select = only_direct || only_plate ? 0 : 1;
       if (!only_plate)
         hipLaunchKernelGGL(sa_forward_linear_fast_kernel, dim3(8u * tiles * groups), block,
