@@ -1294,8 +1294,10 @@ __global__ __launch_bounds__(256) void warp_brick_kernel(FsgDeformK D, const int
       zi = min(max(zi, 0), D.n2 - 1);
       uint32_t l;
       if (fits) {
+        // (explicit LDS address space: with plain pointers the optimiser merges this branch and the global one below into ONE
+        // load through a selected generic pointer -- a flat instruction on the vector-memory path for every "LDS" read)
         const int idx = ((xi - X0) * ey + (yi - Y0)) * pitch + (zi - Z0);
-        l = (S.lab[idx >> 2] >> (8 * (idx & 3))) & 255u;
+        l = (((const __attribute__((address_space(3))) uint32_t*)S.lab)[idx >> 2] >> (8 * (idx & 3))) & 255u;
       } else {
         const int xs = D.flip ? D.n0 - 1 - xi : xi;
         l = src_nn[((size_t)xs * D.n1 + yi) * D.n2 + zi];
@@ -1315,10 +1317,11 @@ __global__ __launch_bounds__(256) void warp_brick_kernel(FsgDeformK D, const int
         if (fits) {
           const int b00 = ((x0 - X0) * ey + (y0 - Y0)) * pitch + (z0 - Z0);
           const int sxl = dx * ey * pitch, syl = dy * pitch;
-          c000 = S.box[b00];             c001 = S.box[b00 + dz];
-          c100 = S.box[b00 + sxl];       c101 = S.box[b00 + sxl + dz];
-          c010 = S.box[b00 + syl];       c011 = S.box[b00 + syl + dz];
-          c110 = S.box[b00 + sxl + syl]; c111 = S.box[b00 + sxl + syl + dz];
+          const __attribute__((address_space(3))) float* B = (const __attribute__((address_space(3))) float*)S.box;
+          c000 = B[b00];             c001 = B[b00 + dz];
+          c100 = B[b00 + sxl];       c101 = B[b00 + sxl + dz];
+          c010 = B[b00 + syl];       c011 = B[b00 + syl + dz];
+          c110 = B[b00 + sxl + syl]; c111 = B[b00 + sxl + syl + dz];
         } else {
           int xs0 = x0, xs1 = x0 + dx;
           if (D.flip) { xs0 = D.n0 - 1 - xs0; xs1 = D.n0 - 1 - xs1; }
