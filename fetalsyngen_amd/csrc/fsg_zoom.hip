@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 8) void zoom1_rows_pf_kernel(ZoomK Z, EpiZ E, 
 //     values and one z-lerp per output (x -> y -> z, the operation order of fsg_tab_interp<1>: bit-identical), one
 //     Philox block per four outputs, one 16-byte store.
 // Falls back to the row kernels when the window does not fit the LDS budget.
-constexpr int ZT_MAX_TY = 32;
+constexpr int ZT_MAX_TY = 64;
 
 template <int EPI>
 __global__ __launch_bounds__(256) void zoom_tile_kernel(ZoomK Z, EpiZ E, int TY, int cap_floats) {
@@ -1012,16 +1012,17 @@ int launch1(const ZoomK& Z, const EpiZ& E, void* stream) {
     // tile height: the kernel's fixed part per workgroup (taps, window bounds, x stage: a chain of global round trips) costs
     // 10-12 us of its 19-27 us at 16 rows per tile (profiles/r02_b_zoom_experiments.txt, ablation).  Twice the rows per
     // workgroup pays for the pass that stores nothing (K9a 19.0 -> 17.3 us); the storing passes lose it again (27.4 -> 28.5)
-    const int ty_pref = EPI == EPI_MINMAX ? 2 * g_zoom_ty : g_zoom_ty;
-    int TY = ty_pref < ZT_MAX_TY ? ty_pref : ZT_MAX_TY;
-    if (TY > Z.dy) TY = Z.dy;
-    long long est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-    long long total = est + 5LL * 256;  // window (+ 256 floats behind it: unclamped column reads) + the four waves' rows (256 each)
-    if (!(est <= g_zoom_cap && total <= 16000)) {
-      TY = g_zoom_ty < ZT_MAX_TY ? g_zoom_ty : ZT_MAX_TY;
+    // r03_h, with the row loop at ~45 instead of ~100 vector instructions: four / two times the rows win again where the window
+    // still fits (m = 128: K9a 15.5 -> 14.3 us at 64 rows, K9b 26.4 -> 24.3 at 32; m = 171: 18.5 -> 17.6 / same; m = 220: same).
+    // The tallest tile whose window fits the LDS budget: 4x, 2x, 1x the tuned height for the min/max pass, 2x, 1x otherwise.
+    int TY = 0;
+    long long est = 0, total = 0;
+    for (int mult = (EPI == EPI_MINMAX ? 4 : 2); mult >= 1; mult >>= 1) {
+      TY = mult * g_zoom_ty < ZT_MAX_TY ? mult * g_zoom_ty : ZT_MAX_TY;
       if (TY > Z.dy) TY = Z.dy;
       est = ((long long)TY * Z.sy / Z.dy + 3) * Z.sz;
-      total = est + 5LL * 256;
+      total = est + 5LL * 256;  // window (+ 256 floats behind it: unclamped column reads) + the four waves' rows (256 each)
+      if (est <= g_zoom_cap && total <= 16000) break;
     }
     if (TY >= 1 && est <= g_zoom_cap && total <= 16000 && Z.sz <= 256 && Z.dz <= 256) {
       const int tiles_y = (Z.dy + TY - 1) / TY;
