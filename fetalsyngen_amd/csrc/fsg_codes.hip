@@ -58,6 +58,7 @@ __device__ __forceinline__ int sc_global_code(const CodesK& P, const uint32_t* c
       }
     }  // st == 1: another lane is writing this slot -- look again
   }
+  atomicAdd(P.count, 2 * SC_SLOTS);  // (unreachable in a table at most half full; if it ever is, the host sees count > cap and keeps the volumes)
   return -1;
 }
 
