@@ -71,7 +71,8 @@ __device__ __forceinline__ uint4 fsg_philox4x32_10(uint32_t c0, uint32_t c1, uin
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
     const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    // three-input xor in one instruction (v_bitop3_b32, truth table 0x96; gfx950): 20 instead of 40 xors per block
+    uint32_t n0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96);
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += W0; k1 += W1;
   }
