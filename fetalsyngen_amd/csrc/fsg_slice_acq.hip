@@ -41,7 +41,7 @@ struct SaParams {
 constexpr int SA_TILE = 16;
 // Direct gathers cost 4.2 + ~10 |T10| + ~35 |T20| ms for the 80 x 320^2 x 441-tap stack of the bench (lanes run along the
 // slice's x axis: its y component spreads a wave's gather over rows, its z component over planes 590 KB apart), the plate
-// kernel 5.7 ms aligned, 6-9 ms for most orientations, up to 18 ms with the x axis along the volume's z
+// kernel 5.7 ms aligned, 6-9.3 ms for every other orientation
 // (profiles/r03_i_slice_acq_forward.txt): direct gathers only win for nearly aligned slices (and a little longer for small PSFs,
 // whose plate set-up weighs more).
 __device__ __forceinline__ float sa_direct_cost(const float* T) { return 10.f * fabsf(T[4]) + 35.f * fabsf(T[8]); }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void sa_forward_plate_kernel(SaParams P, const
           const int ty0 = min(max((int)floorf(cy0 + a1), 0), P.H - 1), ty1 = min(max((int)floorf(cy1 + b1) + 1, 0), P.H - 1);
           const int tz0 = min(max((int)floorf(cz0 + a2), 0), P.D - 1), tz1 = min(max((int)floorf(cz1 + b2) + 1, 0), P.D - 1);
           const int nx = max(tx1 - tx0 + 1, 1), ny = max(ty1 - ty0 + 1, 1), nz = max(tz1 - tz0 + 1, 1);
-          const int pt = nx <= 16 ? 16 : 32;
+          const int pt = nx <= 4 ? 4 : (nx <= 8 ? 8 : (nx <= 16 ? 16 : 32));  // row pitch: a slice tilted towards z has a narrow box along x
           if (nx > 32 || pt * ny * nz > SAP_CAP) break;
           o0 = a0; o1 = a1; o2 = a2; o3 = b0; o4 = b1; o5 = b2;
           X0 = tx0; Y0 = ty0; Z0 = tz0; ex = nx; ey = ny; ez = nz; pitch = pt;
