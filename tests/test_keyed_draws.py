@@ -377,6 +377,19 @@ def test_code_volume_head_is_bit_identical_to_the_four_volume_head(K):
             outs[use] = res
         for a, b in zip(outs[False], outs[True]):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # the library-side A/B switch (FSG_TUNE_NO_SEED_CODES): a plan that carries codes is served from the four volumes
+        from fetalsyngen_amd import _lib as _L
+
+        gen = make_generator(shape, DEV, rng="keyed", **kw)
+        bank = SeedBank(seeds, DEV)
+        _L.load().fsg_set_tuning(65536)
+        try:
+            got = [gen._pipeline(None, seg_d, bank, {}, scale01=True, key=sharding.sample_key(5, i))[:2] for i in range(3)]
+        finally:
+            _L.load().fsg_set_tuning(0)
+        assert getattr(bank, "_seed_codes", None) is not None
+        for a, b in zip(outs[False][:3], got):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         # the selection really changed between samples (otherwise the test would not see a wrong tuple column)
         assert len({tuple(gen.keyed_context(shape).draws(sharding.sample_key(5, i)).subclusters[:4]) for i in range(9)}) > 3
 
