@@ -20,6 +20,15 @@ from .rng import get_mode as get_rng_mode, set_mode as set_rng_mode  # noqa: F40
 
 __version__ = "0.1.0"
 
+import os as _os
+
+if not _os.environ.get("FSG_KEEP_TORCH_THREADS"):
+    # torch's CPU pool sized by the machine inside a container's CPU share stalls the host side for ~90 ms at a time
+    # (hostenv.py); only ever lowers the count
+    from .hostenv import cap_host_threads as _cap
+
+    _cap()
+
 
 def build(force: bool = False):
     """Compile libfsg_hip.so in-tree (hipcc, --offload-arch=gfx950)."""

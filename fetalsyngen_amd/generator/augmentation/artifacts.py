@@ -54,10 +54,14 @@ class BlurCortex(RandTransform):
     def blur_proba(self, shape, seg, device):
         """Sampling probability of each cortex voxel (raster order), host float32 (ref :64-81): two wide blobs on the
         frontal side, read at the cortex voxels and normalised.  `seg`: the float label map (cortex = cortex_label)."""
+        p = self._cortex_weights(shape, seg, device)
+        return p / p.sum()
+
+    def _cortex_weights(self, shape, seg, device):
+        """The blob field at the cortex voxels, not normalised (host float32, raster order)."""
         x, y, z = shape
         prob = K.mog3d(shape, *mog_params([(0, y, z // 2), (x, y, z // 2)], [x // 5, y // 5]), device)
-        p = K.compact_values(prob, seg, "==", float(self.cortex_label)).cpu()
-        return p / p.sum()
+        return K.compact_values(prob, seg, "==", float(self.cortex_label)).cpu()
 
     def __call__(self, output, seg, device, genparams: dict = {}, **kwargs):
         if np.random.rand() < self.prob or len(genparams.keys()) > 0:
@@ -65,8 +69,11 @@ class BlurCortex(RandTransform):
             nblur = np.random.randint(self.nblur_min, self.nblur_max) if "nblur" not in genparams.keys() else genparams["nblur"]
             std_blurs = np.random.gamma(self.std_blur_shape, self.std_blur_scale, 3)
             seg = seg.to(output.device).float().contiguous()
-            cortex_prob = self.blur_proba(output.shape, seg, output.device)
-            idx = _rng.multinomial_distinct(cortex_prob, nblur)  # CPU generator (torch.multinomial in reference mode)
+            # reference mode: the normalised probabilities into torch.multinomial, as the reference (:110); otherwise the
+            # inverse-CDF draw scales by the total itself, and the million-element divide stays off the host
+            cortex_prob = (self.blur_proba(output.shape, seg, output.device) if _rng.get_mode() == "reference"
+                           else self._cortex_weights(output.shape, seg, output.device))
+            idx = _rng.multinomial_distinct(cortex_prob, nblur)  # CPU generator
             count, select = K.nonzero_ranks(seg, "==", float(self.cortex_label))
             centers = select(idx)
             sigmas = np.random.gamma(self.sigma_gamma_loc, self.sigma_gamma_scale, (nblur, 3))

@@ -23,6 +23,7 @@ from __future__ import annotations
 import contextlib
 import os
 
+import numpy as np
 import torch
 
 _MODE = os.environ.get("FSG_RNG", "device")
@@ -107,12 +108,14 @@ def multinomial_distinct(prob: torch.Tensor, k: int) -> torch.Tensor:
     per-element exponential race."""
     if _MODE == "reference" or k >= prob.numel() // 2:
         return torch.multinomial(prob, k)
-    cdf = torch.cumsum(prob.double(), 0)
+    # numpy for the million-element pass: single-threaded by construction (a torch CPU op of this size wakes the whole
+    # intra-op pool, see hostenv.py); the same sequential float64 running sum as torch.cumsum(prob.double())
+    cdf = np.cumsum(prob.numpy(), dtype=np.float64)
     total = float(cdf[-1])
     seen, out = set(), []
     while len(out) < k:
-        u = torch.rand(2 * (k - len(out)) + 8, dtype=torch.float64) * total
-        for v in torch.searchsorted(cdf, u, right=True).clamp_(max=prob.numel() - 1).tolist():
+        u = torch.rand(2 * (k - len(out)) + 8, dtype=torch.float64).numpy() * total
+        for v in np.minimum(np.searchsorted(cdf, u, side="right"), prob.numel() - 1).tolist():
             if v not in seen:
                 seen.add(v)
                 out.append(v)
