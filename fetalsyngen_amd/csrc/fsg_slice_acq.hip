@@ -36,15 +36,18 @@ struct SaParams {
   // sa_direct_cost(T) <= fwd_thr (direct gathers), 2 the others (plate kernel)
   int fwd_select;
   float fwd_thr;
+  float fwd_wy;  // weight of the slice x axis' y component in sa_direct_cost (10 for PSFs of 400 elements and more, 30 below)
 };
 
 constexpr int SA_TILE = 16;
 // Direct gathers cost 4.2 + ~10 |T10| + ~35 |T20| ms for the 80 x 320^2 x 441-tap stack of the bench (lanes run along the
 // slice's x axis: its y component spreads a wave's gather over rows, its z component over planes 590 KB apart), the plate
 // kernel 5.7 ms aligned, 6-9.3 ms for every other orientation
-// (profiles/r03_i_slice_acq_forward.txt): direct gathers only win for nearly aligned slices (and a little longer for small PSFs,
-// whose plate set-up weighs more).
-__device__ __forceinline__ float sa_direct_cost(const float* T) { return 10.f * fabsf(T[4]) + 35.f * fabsf(T[8]); }
+// (profiles/r03_i_slice_acq_forward.txt): direct gathers only win for nearly aligned slices.  For PSFs under 400 elements the
+// plate's set-up weighs more and a z tilt is tolerated longer (crossover 35 |T20| ~ 10 at a pixel pitch of one voxel), but a
+// y tilt is not (crossover |T10| ~ 0.35: the few taps no longer share the rows a wave's gather touches), and both scale with
+// the pixel pitch -- section 8 of the same file, stacks as SimulateMotion draws them.
+__device__ __forceinline__ float sa_direct_cost(const float* T, float wy) { return wy * fabsf(T[4]) + 35.f * fabsf(T[8]); }
 constexpr int SA_MAX_PSF = 4096;  // elements (16 KB of LDS)
 constexpr int SA_MAX_AXIS = 64;
 
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_forward_linear_fast_kerne
   if (in >= P.n) return;
   const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
-  if (P.fwd_select == 1 && sa_direct_cost(T) > P.fwd_thr) return;  // this slice is the plate kernel's (uniform)
+  if (P.fwd_select == 1 && sa_direct_cost(T, P.fwd_wy) > P.fwd_thr) return;  // this slice is the plate kernel's (uniform)
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);  // [<= np] (ox, oy, oz, psf)
   __shared__ int ntaps_s;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void sa_forward_plate_kernel(SaParams P, const
   if (in >= P.n) return;
   const int bx = tile % tiles_x, by = tile / tiles_x;
   const float* __restrict__ T = P.tr + (size_t)in * 12;
-  if (P.fwd_select == 2 && !(sa_direct_cost(T) > P.fwd_thr)) return;  // this slice is the direct kernel's (uniform)
+  if (P.fwd_select == 2 && !(sa_direct_cost(T, P.fwd_wy) > P.fwd_thr)) return;  // this slice is the direct kernel's (uniform)
   const int np = P.pd * P.ph * P.pw;
   float4* taps = reinterpret_cast<float4*>(smem);              // [<= np] (ox, oy, oz, psf), raster order
   int* pstart = reinterpret_cast<int*>(taps + np);             // [pd + 1] first compacted tap of every PSF plane
@@ -985,7 +988,10 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
       // r03: two launches, every slice taken by exactly one of them according to its own orientation (a workgroup of the other
       // launch leaves on its first instructions): direct gathers where the slice's x axis stays near the volume's x-y plane,
       // the plate of the volume in LDS (4 x 4 pixel tiles x 4 tap phases per wave) elsewhere
-      P.fwd_thr = pd * ph * pw < 400 ? 8.0f : 1.7f;  // measured crossovers (101 / 441 / 697 taps)
+      // measured crossovers (101 / 441 / 697 taps at 80 x 320^2; 73-543 taps on the stacks SimulateMotion draws at 384^3)
+      const bool small_psf = pd * ph * pw < 400;
+      P.fwd_wy = small_psf ? 30.f : 10.f;
+      P.fwd_thr = small_psf ? 10.f / fmaxf(res_slice, 0.25f) : 1.7f;
       P.fwd_select = only_direct || only_plate ? 0 : 1;
       if (!only_plate)
         hipLaunchKernelGGL(sa_forward_linear_fast_kernel, dim3(8u * tiles * groups), block,
