@@ -627,18 +627,24 @@ __global__ __launch_bounds__(SA_TILE* SA_TILE) void sa_adjoint_kernel(SaParams P
 //     global atomics.  A cell index outside the box (cannot happen by construction) also falls back.
 // Same sums as the direct kernel up to fp32 summation order (which is nondeterministic there as well).
 // ---------------------------------------------------------------------------------------------------------
+// roundf(x) for 0 <= x < 2^23 in two instructions: floor(x + pred(0.5)).  Ties n + 0.5 still reach n + 1 (the sum rounds up to
+// the integer), and the one value below a tie, n + 0.5 - ulp, stays at n (with + 0.5 the sum for 0.5 - 2^-25 would round to 1).
+__device__ __forceinline__ float sa_round_pos(float x) { return floorf(x + 0.49999997f); }
+
 __device__ __forceinline__ bool sa_psf_at_fast(const SaLds& L, const SaParams& P, const float* __restrict__ T, float dx,
                                                float dy, float dz, float& val) {
   // float adds: fl32(fl64(a + b)) == fl32(a + b) for fp32 a, b (53 >= 2*24 + 2), so no double is needed here
   const float xp = (T[0] * dx + T[4] * dy + T[8] * dz) + (float)(P.pw - 1) * 0.5f;
   const float yp = (T[1] * dx + T[5] * dy + T[9] * dz) + (float)(P.ph - 1) * 0.5f;
   const float zp = (T[2] * dx + T[6] * dy + T[10] * dz) + (float)(P.pd - 1) * 0.5f;
-  if (xp < 0 || yp < 0 || zp < 0 || xp >= (float)(P.pw - 1) || yp >= (float)(P.ph - 1) || zp >= (float)(P.pd - 1))
-    return false;
+  // 0 <= p < n - 1  <=>  (unsigned)floor(p) < n - 1 (n - 1 is an integer; -0.0 and NaN pass both forms): three compares, not six
   const float xf = floorf(xp), yf = floorf(yp), zf = floorf(zp);
+  const int jx = (int)xf, jy = (int)yf, jz = (int)zf;
+  if ((unsigned)jx >= (unsigned)(P.pw - 1) || (unsigned)jy >= (unsigned)(P.ph - 1) || (unsigned)jz >= (unsigned)(P.pd - 1))
+    return false;
   const float wx = xp - xf, wy = yp - yf, wz = zp - zf;
   const int sy = P.pw, sz = P.pw * P.ph;
-  const float* q = L.psf + (int)zf * sz + (int)yf * sy + (int)xf;
+  const float* q = L.psf + jz * sz + jy * sy + jx;
   const float a00 = q[0] + wx * (q[1] - q[0]), a10 = q[sy] + wx * (q[sy + 1] - q[sy]);
   const float a01 = q[sz] + wx * (q[sz + 1] - q[sz]), a11 = q[sz + sy] + wx * (q[sz + sy + 1] - q[sz + sy]);
   const float b0 = a00 + wy * (a10 - a00), b1 = a01 + wy * (a11 - a01);
@@ -680,6 +686,35 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
   const int Sy = P.W, Sz = P.H * P.W;
   const float hx = (float)(P.W - 1), hy = (float)(P.H - 1), hz = (float)(P.D - 1);
 
+  // tile extent in slice coordinates
+  const int ixl = ix0, ixh = min(ix0 + T_ - 1, P.w - 1), iyl = iy0, iyh = min(iy0 + T_ - 1, P.h - 1);
+  const float alo = ((float)ixl - (float)(P.w - 1) * 0.5f) * P.res + T[3] - (float)(P.pw / 2);
+  const float ahi = ((float)ixh - (float)(P.w - 1) * 0.5f) * P.res + T[3] + (float)(P.pw - 1 - P.pw / 2);
+  const float blo = ((float)iyl - (float)(P.h - 1) * 0.5f) * P.res + T[7] - (float)(P.ph / 2);
+  const float bhi = ((float)iyh - (float)(P.h - 1) * 0.5f) * P.res + T[7] + (float)(P.ph - 1 - P.ph / 2);
+  const int dimv[3] = {P.W, P.H, P.D};
+  // axis-aligned box of the positions the tile's pixels can reach through PSF planes [clo, chi] (slice coordinates), clipped to
+  // the volume: origin o, extent b; returns whether the unclipped box lies inside the volume by the fp32 slack of the position
+  // sums -- then no tap of the tile needs the per-tap inside test (uniform)
+  auto reach = [&](float clo, float chi, int* o, int* b) -> bool {
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float r0 = T[a * 4], r1 = T[a * 4 + 1], r2 = T[a * 4 + 2];
+      const float off = (float)(dimv[a] - 1) * 0.5f;
+      const float mn = off + fminf(r0 * alo, r0 * ahi) + fminf(r1 * blo, r1 * bhi) + fminf(r2 * clo, r2 * chi);
+      const float mx = off + fmaxf(r0 * alo, r0 * ahi) + fmaxf(r1 * blo, r1 * bhi) + fmaxf(r2 * clo, r2 * chi);
+      // voxel = round(position): [floor(mn + .5), floor(mx + .5)], widened by the slack
+      const int lo = max((int)floorf(mn + 0.5f - 2e-3f), 0), hi = min((int)floorf(mx + 0.5f + 2e-3f), dimv[a] - 1);
+      o[a] = lo;
+      b[a] = hi - lo + 1;
+      inside = inside && mn - 2e-3f >= 0.f && mx + 2e-3f < (float)(dimv[a] - 1);
+    }
+    return inside;
+  };
+  int o_all[3], b_all[3];
+  const bool inside_all = reach(T[11] + (float)(0 - P.pd / 2), T[11] + (float)(P.pd - 1 - P.pd / 2), o_all, b_all);
+
   // pass 1: pixel weight (slice_acq_cuda_kernel.cu:515-560), PSF rows split over the G waves of a pixel
   float wsum = 0.f;
   if (live) {
@@ -694,8 +729,8 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
           const float x = xc + L.tx[kx] + yx + zx;
           const float y = yc + L.tx[P.pw + kx] + yy + zy;
           const float z = zc_ + L.tx[2 * P.pw + kx] + yz + zz;
-          if (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz) continue;
-          if (!sa_psf_at_fast(L, P, T, roundf(x) - xc, roundf(y) - yc, roundf(z) - zc_, pv)) continue;
+          if (!inside_all && (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz)) continue;
+          if (!sa_psf_at_fast(L, P, T, sa_round_pos(x) - xc, sa_round_pos(y) - yc, sa_round_pos(z) - zc_, pv)) continue;
           wsum += pv;
         }
       }
@@ -711,13 +746,6 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
   if (wsum < 0.5f) live = false;
   const float inv = live ? 1.f / wsum : 0.f;
 
-  // tile extent in slice coordinates (same for every chunk)
-  const int ixl = ix0, ixh = min(ix0 + T_ - 1, P.w - 1), iyl = iy0, iyh = min(iy0 + T_ - 1, P.h - 1);
-  const float alo = ((float)ixl - (float)(P.w - 1) * 0.5f) * P.res + T[3] - (float)(P.pw / 2);
-  const float ahi = ((float)ixh - (float)(P.w - 1) * 0.5f) * P.res + T[3] + (float)(P.pw - 1 - P.pw / 2);
-  const float blo = ((float)iyl - (float)(P.h - 1) * 0.5f) * P.res + T[7] - (float)(P.ph / 2);
-  const float bhi = ((float)iyh - (float)(P.h - 1) * 0.5f) * P.res + T[7] + (float)(P.ph - 1 - P.ph / 2);
-
   // LDS cell layout: a chunk of PSF planes of a pixel tile is an oblique plate in the volume, whose axis-aligned
   // bounding box can hold 10x more cells than the plate.  Cells are therefore indexed by the two volume axes (u, v)
   // other than the one the slice normal leans on most (a), plus the offset k of the a-coordinate from the plate's
@@ -727,7 +755,6 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
   const int U = A == 0 ? 1 : 0, V = A == 2 ? 1 : 2;  // U < V, so x is U whenever x is not the lean axis
   const float nA = A == 0 ? n0 : (A == 1 ? n1 : n2), nU = U == 0 ? n0 : n1, nV = V == 1 ? n1 : n2;
   const float inv_na = 1.f / nA, slope = (fabsf(nU) + fabsf(nV)) * fabsf(inv_na);
-  const int dimv[3] = {P.W, P.H, P.D};
   // tile centre in slice coordinates -> a point of the mid-plane (per chunk: its z)
   const float amid = 0.5f * (alo + ahi), bmid = 0.5f * (blo + bhi);
 
@@ -735,17 +762,7 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
     const int kz1 = min(kz0 + zc, P.pd);
     const float clo = T[11] + (float)(kz0 - P.pd / 2), chi = T[11] + (float)(kz1 - 1 - P.pd / 2);
     int o[3], b[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float r0 = T[a * 4], r1 = T[a * 4 + 1], r2 = T[a * 4 + 2];
-      const float off = (float)(dimv[a] - 1) * 0.5f;
-      const float mn = off + fminf(r0 * alo, r0 * ahi) + fminf(r1 * blo, r1 * bhi) + fminf(r2 * clo, r2 * chi);
-      const float mx = off + fmaxf(r0 * alo, r0 * ahi) + fmaxf(r1 * blo, r1 * bhi) + fmaxf(r2 * clo, r2 * chi);
-      // voxel = round(position): [floor(mn + .5), floor(mx + .5)], widened by the fp32 slack of the position sums
-      const int lo = max((int)floorf(mn + 0.5f - 2e-3f), 0), hi = min((int)floorf(mx + 0.5f + 2e-3f), dimv[a] - 1);
-      o[a] = lo;
-      b[a] = hi - lo + 1;
-    }
+    const bool inside = reach(clo, chi, o, b);
     if (b[0] <= 0 || b[1] <= 0 || b[2] <= 0) continue;  // the chunk cannot reach the volume (uniform)
     const float cmid = 0.5f * (clo + chi);
     float pm[3];  // mid-plane point in volume coordinates
@@ -776,8 +793,8 @@ __global__ __launch_bounds__(256) void sa_adjoint_nn_lds_kernel(SaParams P, cons
             const float x = xc + L.tx[kx] + yx + zx;
             const float y = yc + L.tx[P.pw + kx] + yy + zy;
             const float z = zc_ + L.tx[2 * P.pw + kx] + yz + zz;
-            if (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz) continue;
-            const float xr = roundf(x), yr = roundf(y), zr = roundf(z);
+            if (!inside && (x < 0 || y < 0 || z < 0 || x >= hx || y >= hy || z >= hz)) continue;
+            const float xr = sa_round_pos(x), yr = sa_round_pos(y), zr = sa_round_pos(z);
             if (!sa_psf_at_fast(L, P, T, xr - xc, yr - yc, zr - zc_, pv)) continue;
             pv *= inv;
             const int vv[3] = {(int)xr, (int)yr, (int)zr};
