@@ -1000,7 +1000,8 @@ int fsg_slice_acq_forward_f32(const float* transforms, const float* vol, const u
       const unsigned tiles = grid.x * grid.y, groups = (unsigned)((n + 7) / 8);
       const size_t lds_p = (size_t)pd * ph * pw * 4 * sizeof(float) + (size_t)(pd + 1) * sizeof(int) + (size_t)6 * pd * sizeof(float) +
                            16 + (size_t)4 * SAP_CAP * sizeof(float);
-      const bool only_direct = (g_tuning_flags & FSG_TUNE_SA_FWD_DIRECT) || lds_p > 64000;
+      // a single tap (the mask acquisition of Scanner.scan) is a plain 2x2x2 gather per pixel: nothing for a plate to reuse
+      const bool only_direct = (g_tuning_flags & FSG_TUNE_SA_FWD_DIRECT) || lds_p > 64000 || pd * ph * pw == 1;
       const bool only_plate = !only_direct && (g_tuning_flags & FSG_TUNE_SA_FWD_PLATE);
       // r03: two launches, every slice taken by exactly one of them according to its own orientation (a workgroup of the other
       // launch leaves on its first instructions): direct gathers where the slice's x axis stays near the volume's x-y plane,
